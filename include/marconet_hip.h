@@ -1,0 +1,181 @@
+/*
+ * marconet_hip.h — C-ABI of libmarconet_hip.so: hand-written gfx950 (MI355X / CDNA4) kernels for the
+ * MARCONet test_sr.py / test_w.py inference forward.
+ *
+ * Boundary rules:
+ *   - plain C: raw device pointers, ints, a dtype enum and a hipStream_t (passed as void*); no torch types
+ *   - every buffer (inputs, outputs, workspaces) is owned and allocated by the caller
+ *   - every call enqueues work on the given stream and returns; no call synchronises or allocates
+ *   - return value: 0 = ok, negative = MNET_E_* ; mnet_last_error() returns a thread-local message
+ *   - re-entrant, no mutable global state
+ *
+ * The reference has no native layer of its own: its operator layer is ATen + one third-party CUDA op
+ * (basicsr.ops.fused_act, models/networks.py:10).  Each entry point below therefore cites the reference
+ * *call sites* (file:line under /root/reference) whose arithmetic it replaces.
+ *
+ * Tensor layout: activations are NHWC ("pixel-major, channel-minor") in MNET_F32 or MNET_F16; conv
+ * weights are [Cout][KH][KW][Cin] in the same dtype.  All statistics, softmax, demodulation and
+ * epilogue math are fp32 (fp64 for the GroupNorm / AdaIN sums).
+ */
+#ifndef MARCONET_HIP_H
+#define MARCONET_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MNET_ABI_VERSION 1
+
+typedef enum { MNET_F32 = 0, MNET_F16 = 1 } mnet_dtype;
+
+typedef enum {
+    MNET_ACT_NONE = 0,
+    MNET_ACT_RELU = 1,          /* models/resnet.py:16,24,29                                   */
+    MNET_ACT_LRELU = 2,         /* nn.LeakyReLU(0.2), models/networks.py:337..404              */
+    MNET_ACT_LRELU_SQRT2 = 3,   /* basicsr fused_leaky_relu: sqrt(2)*lrelu_0.2, networks.py:195,241 */
+    MNET_ACT_TANH = 4,          /* networks.py:321,375                                         */
+    MNET_ACT_GELU = 5,          /* nn.GELU() exact erf, models/textvit_arch.py:49,88           */
+    MNET_ACT_SIGMOID = 6        /* textvit_arch.py:51                                          */
+} mnet_act;
+
+enum {
+    MNET_OK = 0,
+    MNET_E_ARG = -1,        /* bad shape / null pointer / unsupported combination */
+    MNET_E_ALIGN = -2,      /* pointer or channel count not aligned as required   */
+    MNET_E_LAUNCH = -3      /* hipLaunchKernel / hipFuncSetAttribute failed       */
+};
+
+const char* mnet_last_error(void);
+int mnet_abi_version(void);
+
+/* ---------------------------------------------------------------------------------------------
+ * mnet_conv2d_nhwc — implicit-GEMM convolution on the matrix cores (MFMA 16x16x32 f16 / 16x16x4 f32),
+ * with fused prologue and epilogue.  One entry point covers:
+ *   K1/K2/K3 dense 3x3 / 1x1 / strided convs  models/resnet.py:4-9,21-30 ; models/networks.py:336-405,501-505
+ *   K4  modulated conv (activation-side modulation: y = demod[n,o] * conv(W*scale, x * s[n,i]))
+ *                                              models/networks.py:281-302 (ModulatedConv2d.forward)
+ *   K5  fused bias + LeakyReLU*sqrt2 epilogue  basicsr fused_act, call sites networks.py:195,241-245
+ *   K7  every nn.Linear of TextViT / style MLP (1x1 conv over a [1,1,M,K] map)
+ *                                              models/textvit_arch.py:34,49-60,84-107 ; networks.py:188-198
+ *       the 8x8/stride-8 patch embedding is the same kernel with kh=kw=8 (textvit_arch.py:32-35)
+ *   K17 channel concat without materialising it (two sources)   networks.py:415-416
+ *   K11 GroupNorm+swish as an input-side affine (scale/shift per (n,c)) + swish   networks.py:508-513
+ *
+ * y[n,oh,ow,o] = act( out_scale[n,o] * sum_{r,s,i} W[o,r,s,i] * X'[n, oh*sh-ph+r, ow*sw-pw+s, i]
+ *                     + bias[o] + residual[n,oh,ow,o] )
+ *   X' = X                                   if in_scale == NULL
+ *   X' = f(X * in_scale[n,i] + in_shift[n,i]),  f = swish if in_swish else identity
+ *   X  = channel-concat(x0[..c0], x1[..c1]);  out-of-image taps (and columns >= valid_w[n]) are zero
+ *
+ * Requirements: (c0+c1) % 8 == 0, c0 % 8 == 0, cout % 4 == 0, all pointers 16-byte aligned.
+ * ------------------------------------------------------------------------------------------- */
+typedef struct {
+    int32_t dtype;              /* mnet_dtype of x0, x1, wgt, residual, y                         */
+    const void* x0; int32_t c0; /* NHWC [n,h,w,c0]                                                */
+    const void* x1; int32_t c1; /* NHWC [n,h,w,c1] or NULL/0                                      */
+    int32_t n, h, w;
+    const void* wgt;            /* [cout][kh][kw][c0+c1]                                          */
+    int32_t cout, kh, kw, stride_h, stride_w, pad_h, pad_w;
+    int32_t ho, wo;             /* output spatial size (caller computes)                          */
+    const float* in_scale;      /* [n][cin] or NULL                                               */
+    const float* in_shift;      /* [n][cin] or NULL (treated as 0)                                */
+    int32_t in_swish;
+    const int32_t* valid_w;     /* [n] or NULL: input columns >= valid_w[n] read as zero          */
+    const float* out_scale;     /* [n][cout] or NULL (demodulation)                               */
+    const float* bias;          /* [cout] fp32 or NULL                                            */
+    const void* residual;       /* NHWC like y, or NULL                                           */
+    int32_t res_mod;            /* 0, or residual pixel index = pixel % res_mod (pos-emb add)     */
+    int32_t act;                /* mnet_act, applied after bias+residual                          */
+    void* y;                    /* NHWC [n,ho,wo,cout]                                            */
+} mnet_conv_desc;
+
+int mnet_conv2d_nhwc(const mnet_conv_desc* d, void* stream);
+
+/* 2*MACs of the launch described by d (for roofline accounting in bench.py) */
+double mnet_conv2d_flops(const mnet_conv_desc* d);
+
+/* ---------------------------------------------------------------------------------------------
+ * layout changes at the module boundary (reference tensors are NCHW fp32, models/networks.py:42,61,411)
+ * ------------------------------------------------------------------------------------------- */
+/* src fp32 NCHW [n,c,h,w] -> dst NHWC [n,h,w,c_ld] (channels c..c_ld-1 written as zero) */
+int mnet_nchw_to_nhwc(const float* src, void* dst, int32_t dst_dtype, int32_t n, int32_t c, int32_t h,
+                      int32_t w, int32_t c_ld, void* stream);
+/* src NHWC [n,h,w,c_ld] (first c channels used) -> dst fp32 NCHW [n,c,h,w] */
+int mnet_nhwc_to_nchw(const void* src, int32_t src_dtype, float* dst, int32_t n, int32_t c, int32_t h,
+                      int32_t w, int32_t c_ld, void* stream);
+
+/* K6: bilinear x2, align_corners=False (== polyphase [1/4,3/4] with edge clamp), NHWC, c % 4 == 0 (f32)
+ * / c % 8 == 0 (f16).  nn.Upsample / F.interpolate at networks.py:268,318,360,370,415,416 */
+int mnet_upsample2x_nhwc(const void* src, void* dst, int32_t dtype, int32_t n, int32_t h, int32_t w,
+                         int32_t c, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * K11 GroupNorm statistics (groups of 32 channels, eps, affine), networks.py:487-490 — produces the
+ * per-(n,channel) affine consumed by mnet_conv2d_nhwc's prologue:
+ *   scale[n,c] = rstd[n,g]*gamma[c] ; shift[n,c] = beta[c] - mean[n,g]*rstd[n,g]*gamma[c]
+ * Statistics are over h x valid_w[n] x 32 channels (biased variance), accumulated in fp64.
+ * partial: caller workspace of  n * slices * (c/32) * 2  doubles.
+ * ------------------------------------------------------------------------------------------- */
+int mnet_groupnorm_affine(const void* x, int32_t dtype, int32_t n, int32_t h, int32_t w, int32_t c,
+                          const int32_t* valid_w, const float* gamma, const float* beta, float eps,
+                          double* partial, int32_t slices, float* scale, float* shift, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * per-glyph prior transform of TSPSRNet (networks.py:421-449 and :455-482)
+ * Glyph g belongs to image g_img[g]; it covers feature columns [g_x1[g], g_x1[g]+g_w[g]) and prior
+ * columns [g_y1[g], g_y1[g]+g_w[g]);  S = prior size (32 or 64) = feature height = max window width.
+ * ------------------------------------------------------------------------------------------- */
+/* K12+K13 crop + AdaIN + concat:  out [G,S,S,2C]
+ *   out[g,y,x,0:C]  = (prior[g,y,y1+x,:] - mean_p)/std_p * std_f + mean_f   (unbiased var + 1e-5, :518-533)
+ *   out[g,y,x,C:2C] = feat[img,y,x1+x,:]                                    for x < g_w[g]; 0 beyond */
+int mnet_adain_crop_concat(const void* prior, const void* feat, void* out, int32_t dtype, int32_t G,
+                           int32_t S, int32_t C, int32_t feat_w, const int32_t* g_img,
+                           const int32_t* g_x1, const int32_t* g_y1, const int32_t* g_w, void* stream);
+
+/* K13 ordered scatter:  out[b,y,x,:] = feat + (feat*scale[g,y,x-x1,:] + shift[g,y,x-x1,:]) for the LAST
+ * glyph g of image b whose window covers x (later glyph overwrites earlier, :448,481); out = feat where
+ * no window covers x.  Glyphs of image b are g_start[b] .. g_start[b+1]-1. */
+int mnet_glyph_scatter_affine(const void* feat, const void* scale, const void* shift, void* out,
+                              int32_t dtype, int32_t B, int32_t S, int32_t C, int32_t feat_w,
+                              const int32_t* g_start, const int32_t* g_x1, const int32_t* g_w,
+                              void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * TextViT pieces (fp32 only), models/textvit_arch.py
+ * ------------------------------------------------------------------------------------------- */
+/* K9 LayerNorm over the last dim (eps 1e-5, biased var): y[r,:] = (x[r,:]-mean)*rstd*gamma+beta */
+int mnet_layernorm(const float* x, const float* gamma, const float* beta, float* y, int32_t rows,
+                   int32_t d, float eps, void* stream);
+/* K9 token-axis LayerNorm + Linear (linear_seq_maxlen :141-144,155 ; linear_w_maxlen :59-62,72):
+ *   y[b,j,d] = bias[j] + sum_t W[j,t] * LN_t(x[b,:,d])[t]      x [B,T,D], y [B,J,D], T <= 64 */
+int mnet_token_mix(const float* x, const float* ln_g, const float* ln_b, const float* wgt,
+                   const float* bias, float* y, int32_t B, int32_t T, int32_t D, int32_t J, float eps,
+                   void* stream);
+/* K8 softmax(q k^T * scale) v per (batch, head); qkv [B,N,3*H*64] packed (q|k|v, each '(h d)'),
+ * out [B,N,H*64]; N <= 64, head dim 64   (textvit_arch.py:104-112) */
+int mnet_attention(const float* qkv, float* out, int32_t B, int32_t N, int32_t H, float scale,
+                   void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * TSPGAN pieces, models/networks.py
+ * ------------------------------------------------------------------------------------------- */
+/* K15 PixelNorm: y = x * rsqrt(mean(x^2, dim=1) + 1e-8)   (:170-171), x [N,D] fp32 */
+int mnet_pixelnorm(const float* x, float* y, int32_t N, int32_t D, void* stream);
+/* K14 SelectText: out NHWC [N,4,4*nc,C] = emb[labels[i,j],:] tiled 4x4, chars side by side (:205-215).
+ * labels int64 [N,nc]; returns MNET_E_ARG-free: out-of-range labels must be rejected by the caller. */
+int mnet_embed_gather(const float* emb, const int64_t* labels, void* out, int32_t dtype, int32_t N,
+                      int32_t nc, int32_t C, int32_t num_classes, void* stream);
+/* demod[n,o] = rsqrt( sum_i style[n,i]^2 * wsq_t[i,o] + 1e-8 ),  wsq_t[i,o] = scale^2 * sum_k W[o,i,k]^2
+ * (ModulatedConv2d :284-287 rewritten for activation-side modulation) */
+int mnet_demod(const float* style, const float* wsq_t, float* demod, int32_t N, int32_t cin,
+               int32_t cout, void* stream);
+
+/* argmax over the last dim (first maximal index, like torch.max(...,1)[1] in test_w.py:36) */
+int mnet_argmax_rows(const float* x, int64_t* idx, int32_t rows, int32_t d, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MARCONET_HIP_H */

@@ -1,0 +1,439 @@
+// HBM-bound and small kernels around the implicit-GEMM conv: layout changes, bilinear x2, GroupNorm
+// statistics, the per-glyph AdaIN/crop and ordered scatter of TSPSRNet, SelectText gather, PixelNorm,
+// demodulation.  All move 16-byte chunks per lane along the channel-minor (NHWC) axis, so a wave
+// touches 1 KiB of contiguous memory per instruction; reductions use fp64 partial sums and
+// wave64 butterflies, no atomics (results are bit-reproducible run to run).
+#include "common.h"
+
+// ============================================================================ layout: NCHW fp32 <-> NHWC T
+template <typename T>
+__global__ void __launch_bounds__(256) nchw_to_nhwc_kernel(const float* __restrict__ src, T* __restrict__ dst,
+                                                           int C, int HW, int Cld) {
+    // tile: 32 channels x 32 pixels through LDS (transpose), block (32, 8)
+    __shared__ float tile[32][33];
+    const int n = blockIdx.z, c0 = blockIdx.y * 32, p0 = blockIdx.x * 32;
+    const int tx = threadIdx.x, ty = threadIdx.y;
+    const float* s = src + (size_t)n * C * HW;
+    for (int j = ty; j < 32; j += 8) {
+        const int c = c0 + j, p = p0 + tx;
+        tile[j][tx] = (c < C && p < HW) ? s[(size_t)c * HW + p] : 0.f;
+    }
+    __syncthreads();
+    T* d = dst + (size_t)n * HW * Cld;
+    for (int j = ty; j < 32; j += 8) {
+        const int p = p0 + j, c = c0 + tx;
+        if (p < HW && c < Cld) d[(size_t)p * Cld + c] = (T)tile[tx][j];
+    }
+}
+
+template <typename T>
+__global__ void __launch_bounds__(256) nhwc_to_nchw_kernel(const T* __restrict__ src, float* __restrict__ dst,
+                                                           int C, int HW, int Cld) {
+    __shared__ float tile[32][33];
+    const int n = blockIdx.z, c0 = blockIdx.y * 32, p0 = blockIdx.x * 32;
+    const int tx = threadIdx.x, ty = threadIdx.y;
+    const T* s = src + (size_t)n * HW * Cld;
+    for (int j = ty; j < 32; j += 8) {
+        const int p = p0 + j, c = c0 + tx;
+        tile[j][tx] = (p < HW && c < C) ? (float)s[(size_t)p * Cld + c] : 0.f;
+    }
+    __syncthreads();
+    float* d = dst + (size_t)n * C * HW;
+    for (int j = ty; j < 32; j += 8) {
+        const int c = c0 + j, p = p0 + tx;
+        if (c < C && p < HW) d[(size_t)c * HW + p] = tile[tx][j];
+    }
+}
+
+extern "C" int mnet_nchw_to_nhwc(const float* src, void* dst, int32_t dst_dtype, int32_t n, int32_t c, int32_t h,
+                                 int32_t w, int32_t c_ld, void* stream) {
+    MNET_CHECK_ARG(src && dst && n > 0 && c > 0 && h > 0 && w > 0 && c_ld >= c, "nchw_to_nhwc: bad args");
+    MNET_CHECK_ARG(dst_dtype == MNET_F32 || dst_dtype == MNET_F16, "nchw_to_nhwc: bad dtype");
+    MNET_CHECK_ARG(n <= 65535 && (c_ld + 31) / 32 <= 65535, "nchw_to_nhwc: grid too large");
+    const int HW = h * w;
+    dim3 grid((HW + 31) / 32, (c_ld + 31) / 32, n), block(32, 8);
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    if (dst_dtype == MNET_F16) hipLaunchKernelGGL(nchw_to_nhwc_kernel<f16>, grid, block, 0, st, src, (f16*)dst, c, HW, c_ld);
+    else hipLaunchKernelGGL(nchw_to_nhwc_kernel<float>, grid, block, 0, st, src, (float*)dst, c, HW, c_ld);
+    MNET_LAUNCH_CHECK("nchw_to_nhwc");
+    return MNET_OK;
+}
+
+extern "C" int mnet_nhwc_to_nchw(const void* src, int32_t src_dtype, float* dst, int32_t n, int32_t c, int32_t h,
+                                 int32_t w, int32_t c_ld, void* stream) {
+    MNET_CHECK_ARG(src && dst && n > 0 && c > 0 && h > 0 && w > 0 && c_ld >= c, "nhwc_to_nchw: bad args");
+    MNET_CHECK_ARG(src_dtype == MNET_F32 || src_dtype == MNET_F16, "nhwc_to_nchw: bad dtype");
+    MNET_CHECK_ARG(n <= 65535 && (c + 31) / 32 <= 65535, "nhwc_to_nchw: grid too large");
+    const int HW = h * w;
+    dim3 grid((HW + 31) / 32, (c + 31) / 32, n), block(32, 8);
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    if (src_dtype == MNET_F16) hipLaunchKernelGGL(nhwc_to_nchw_kernel<f16>, grid, block, 0, st, (const f16*)src, dst, c, HW, c_ld);
+    else hipLaunchKernelGGL(nhwc_to_nchw_kernel<float>, grid, block, 0, st, (const float*)src, dst, c, HW, c_ld);
+    MNET_LAUNCH_CHECK("nhwc_to_nchw");
+    return MNET_OK;
+}
+
+// ============================================================================ bilinear x2 (align_corners=False)
+// out row 2j   = 1/4 * in[j-1] + 3/4 * in[j]     (j-1 clamped to 0)
+// out row 2j+1 = 3/4 * in[j]   + 1/4 * in[j+1]   (j+1 clamped to H-1)        same along W
+template <typename T>
+__global__ void __launch_bounds__(256) upsample2x_kernel(const T* __restrict__ src, T* __restrict__ dst,
+                                                         int H, int W, int C, long long total_chunks) {
+    constexpr int N = Vec<T>::N;
+    const int cpp = C / N;     // chunks per pixel
+    for (long long id = (long long)blockIdx.x * blockDim.x + threadIdx.x; id < total_chunks;
+         id += (long long)gridDim.x * blockDim.x) {
+        const int ch = (int)(id % cpp);
+        long long pix = id / cpp;
+        const int ox = (int)(pix % (2 * W)); pix /= (2 * W);
+        const int oy = (int)(pix % (2 * H));
+        const int n = (int)(pix / (2 * H));
+        const int jy = oy >> 1, jx = ox >> 1;
+        int y0, y1, x0, x1; float wy0, wy1, wx0, wx1;
+        if (oy & 1) { y0 = jy; y1 = min(jy + 1, H - 1); wy0 = 0.75f; wy1 = 0.25f; }
+        else { y0 = max(jy - 1, 0); y1 = jy; wy0 = 0.25f; wy1 = 0.75f; }
+        if (ox & 1) { x0 = jx; x1 = min(jx + 1, W - 1); wx0 = 0.75f; wx1 = 0.25f; }
+        else { x0 = max(jx - 1, 0); x1 = jx; wx0 = 0.25f; wx1 = 0.75f; }
+        const T* base = src + (size_t)n * H * W * C + (size_t)ch * N;
+        float a[N], b[N], c[N], d[N], o[N];
+        Vec<T>::unpack(ldg16(base + ((size_t)y0 * W + x0) * C), a);
+        Vec<T>::unpack(ldg16(base + ((size_t)y0 * W + x1) * C), b);
+        Vec<T>::unpack(ldg16(base + ((size_t)y1 * W + x0) * C), c);
+        Vec<T>::unpack(ldg16(base + ((size_t)y1 * W + x1) * C), d);
+#pragma unroll
+        for (int j = 0; j < N; ++j) o[j] = wy0 * (wx0 * a[j] + wx1 * b[j]) + wy1 * (wx0 * c[j] + wx1 * d[j]);
+        stg16(dst + (size_t)id * N, Vec<T>::pack(o));
+    }
+}
+
+extern "C" int mnet_upsample2x_nhwc(const void* src, void* dst, int32_t dtype, int32_t n, int32_t h, int32_t w,
+                                    int32_t c, void* stream) {
+    MNET_CHECK_ARG(src && dst && n > 0 && h > 0 && w > 0 && c > 0, "upsample2x: bad args");
+    MNET_CHECK_ARG(dtype == MNET_F32 || dtype == MNET_F16, "upsample2x: bad dtype");
+    const int N = dtype == MNET_F16 ? 8 : 4;
+    MNET_CHECK_ALIGN(c % N == 0 && aligned16(src) && aligned16(dst), "upsample2x: c %% %d != 0 or unaligned", N);
+    const long long total = (long long)n * 2 * h * 2 * w * (c / N);
+    const int blocks = (int)((total + 255) / 256 < 16384 ? (total + 255) / 256 : 16384);
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    if (dtype == MNET_F16) hipLaunchKernelGGL(upsample2x_kernel<f16>, dim3(blocks), dim3(256), 0, st, (const f16*)src, (f16*)dst, h, w, c, total);
+    else hipLaunchKernelGGL(upsample2x_kernel<float>, dim3(blocks), dim3(256), 0, st, (const float*)src, (float*)dst, h, w, c, total);
+    MNET_LAUNCH_CHECK("upsample2x");
+    return MNET_OK;
+}
+
+// ============================================================================ GroupNorm statistics -> affine
+// stage 1: grid (slices, n). thread t owns chunk column (t % cpp) and pixel lane (t / cpp); it walks the
+// pixels of its slice accumulating sum / sum of squares in fp64 (masked by valid_w); an LDS pass folds
+// the threads of one group; partial[n][slice][group][2].
+template <typename T>
+__global__ void __launch_bounds__(256) gn_partial_kernel(const T* __restrict__ x, int H, int W, int C,
+                                                         const int* __restrict__ valid_w,
+                                                         double* __restrict__ partial, int slices) {
+    constexpr int N = Vec<T>::N;
+    __shared__ double red[256][2];
+    const int n = blockIdx.y, sl = blockIdx.x, t = threadIdx.x;
+    const int cpp = C / N, plane = 256 / cpp;     // cpp divides 256 (checked on host)
+    const int ch = t % cpp, pl = t / cpp;
+    const int vw = valid_w ? min(valid_w[n], W) : W;
+    const int HW = H * W;
+    const int per = (HW + slices - 1) / slices;
+    const int p_begin = sl * per, p_end = min(HW, p_begin + per);
+    double s = 0.0, ss = 0.0;
+    const T* base = x + (size_t)n * HW * C + (size_t)ch * N;
+    for (int p = p_begin + pl; p < p_end; p += plane) {
+        if ((p % W) >= vw) continue;
+        float v[N];
+        Vec<T>::unpack(ldg16(base + (size_t)p * C), v);
+        float a = 0.f, b = 0.f;
+#pragma unroll
+        for (int j = 0; j < N; ++j) { a += v[j]; b += v[j] * v[j]; }
+        s += (double)a; ss += (double)b;
+    }
+    red[t][0] = s; red[t][1] = ss;
+    __syncthreads();
+    const int G = C / 32, cpg = 32 / N;           // chunks per group
+    if (t < G) {
+        double S = 0.0, SS = 0.0;
+        for (int pl2 = 0; pl2 < plane; ++pl2)
+            for (int k = 0; k < cpg; ++k) { const int u = pl2 * cpp + t * cpg + k; S += red[u][0]; SS += red[u][1]; }
+        double* o = partial + (((size_t)n * slices + sl) * G + t) * 2;
+        o[0] = S; o[1] = SS;
+    }
+}
+
+// stage 2: one thread per (n, channel)
+__global__ void gn_finalize_kernel(const double* __restrict__ partial, int slices, int n_img, int H, int W, int C,
+                                   const int* __restrict__ valid_w, const float* __restrict__ gamma,
+                                   const float* __restrict__ beta, float eps, float* __restrict__ scale,
+                                   float* __restrict__ shift) {
+    const int id = blockIdx.x * blockDim.x + threadIdx.x;
+    if (id >= n_img * C) return;
+    const int n = id / C, c = id - n * C, G = C / 32, g = c / 32;
+    double S = 0.0, SS = 0.0;
+    for (int sl = 0; sl < slices; ++sl) {
+        const double* o = partial + (((size_t)n * slices + sl) * G + g) * 2;
+        S += o[0]; SS += o[1];
+    }
+    const int vw = valid_w ? min(valid_w[n], W) : W;
+    const double cnt = (double)H * vw * 32.0;
+    const double mean = S / cnt;
+    double var = SS / cnt - mean * mean;
+    if (var < 0.0) var = 0.0;
+    const float rstd = (float)(1.0 / sqrt(var + (double)eps));
+    const float ga = gamma[c] * rstd;
+    scale[id] = ga;
+    shift[id] = beta[c] - (float)mean * ga;
+}
+
+extern "C" int mnet_groupnorm_affine(const void* x, int32_t dtype, int32_t n, int32_t h, int32_t w, int32_t c,
+                                     const int32_t* valid_w, const float* gamma, const float* beta, float eps,
+                                     double* partial, int32_t slices, float* scale, float* shift, void* stream) {
+    MNET_CHECK_ARG(x && gamma && beta && partial && scale && shift, "groupnorm: null pointer");
+    MNET_CHECK_ARG(n > 0 && h > 0 && w > 0 && c > 0 && slices > 0 && n <= 65535, "groupnorm: bad geometry");
+    MNET_CHECK_ARG(dtype == MNET_F32 || dtype == MNET_F16, "groupnorm: bad dtype");
+    const int N = dtype == MNET_F16 ? 8 : 4;
+    MNET_CHECK_ALIGN(c % 32 == 0 && 256 % (c / N) == 0 && aligned16(x), "groupnorm: c=%d unsupported", c);
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    if (dtype == MNET_F16) hipLaunchKernelGGL(gn_partial_kernel<f16>, dim3(slices, n), dim3(256), 0, st, (const f16*)x, h, w, c, valid_w, partial, slices);
+    else hipLaunchKernelGGL(gn_partial_kernel<float>, dim3(slices, n), dim3(256), 0, st, (const float*)x, h, w, c, valid_w, partial, slices);
+    MNET_LAUNCH_CHECK("gn_partial");
+    const int tot = n * c;
+    hipLaunchKernelGGL(gn_finalize_kernel, dim3((tot + 255) / 256), dim3(256), 0, st, partial, slices, n, h, w, c,
+                       valid_w, gamma, beta, eps, scale, shift);
+    MNET_LAUNCH_CHECK("gn_finalize");
+    return MNET_OK;
+}
+
+// ============================================================================ AdaIN + crop + concat (per glyph)
+// one workgroup per glyph. pass 1: fp64 sums of the prior crop and the feature crop per channel;
+// pass 2: write [S,S,2C] (zeros beyond the glyph's width).
+template <typename T>
+__global__ void __launch_bounds__(256) adain_crop_kernel(const T* __restrict__ prior, const T* __restrict__ feat,
+                                                         T* __restrict__ out, int S, int C, int FW,
+                                                         const int* __restrict__ g_img, const int* __restrict__ g_x1,
+                                                         const int* __restrict__ g_y1, const int* __restrict__ g_w) {
+    constexpr int N = Vec<T>::N;
+    extern __shared__ __attribute__((aligned(16))) unsigned char dyn[];
+    const int g = blockIdx.x, t = threadIdx.x;
+    const int cpp = C / N, plane = 256 / cpp;
+    const int ch = t % cpp, pl = t / cpp;
+    const int img = g_img[g], x1 = g_x1[g], y1 = g_y1[g], gw = g_w[g];
+    double* red = reinterpret_cast<double*>(dyn);                       // [256][N][4]  (only N*4 per thread)
+    float* stat = reinterpret_cast<float*>(dyn + (size_t)256 * N * 4 * sizeof(double));   // [4][C]: pm, ps, fm, fs
+    const T* pbase = prior + (size_t)g * S * S * C + (size_t)ch * N;
+    const T* fbase = feat + (size_t)img * S * FW * C + (size_t)ch * N;
+    const int npx = S * gw;
+    double ps_[N], pss[N], fs_[N], fss[N];
+#pragma unroll
+    for (int j = 0; j < N; ++j) { ps_[j] = pss[j] = fs_[j] = fss[j] = 0.0; }
+    for (int p = pl; p < npx; p += plane) {
+        const int y = p / gw, x = p - y * gw;
+        float a[N], b[N];
+        Vec<T>::unpack(ldg16(pbase + ((size_t)y * S + (y1 + x)) * C), a);
+        Vec<T>::unpack(ldg16(fbase + ((size_t)y * FW + (x1 + x)) * C), b);
+#pragma unroll
+        for (int j = 0; j < N; ++j) {
+            ps_[j] += (double)a[j]; pss[j] += (double)a[j] * (double)a[j];
+            fs_[j] += (double)b[j]; fss[j] += (double)b[j] * (double)b[j];
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < N; ++j) {
+        double* r = red + ((size_t)t * N + j) * 4;
+        r[0] = ps_[j]; r[1] = pss[j]; r[2] = fs_[j]; r[3] = fss[j];
+    }
+    __syncthreads();
+    // thread c (< C) folds the pixel lanes of channel c
+    for (int c = t; c < C; c += 256) {
+        const int chn = c / N, j = c % N;
+        double a0 = 0, a1 = 0, b0 = 0, b1 = 0;
+        for (int q = 0; q < plane; ++q) {
+            const double* r = red + ((size_t)(q * cpp + chn) * N + j) * 4;
+            a0 += r[0]; a1 += r[1]; b0 += r[2]; b1 += r[3];
+        }
+        const double cnt = (double)npx;
+        const double pm = a0 / cnt, fm = b0 / cnt;
+        // unbiased variance (torch .var default, networks.py:522) + eps 1e-5, then sqrt
+        double pv = (a1 - cnt * pm * pm) / (cnt - 1.0), fv = (b1 - cnt * fm * fm) / (cnt - 1.0);
+        if (pv < 0) pv = 0; if (fv < 0) fv = 0;
+        stat[c] = (float)pm; stat[C + c] = sqrtf((float)pv + 1e-5f);
+        stat[2 * C + c] = (float)fm; stat[3 * C + c] = sqrtf((float)fv + 1e-5f);
+    }
+    __syncthreads();
+    T* obase = out + (size_t)g * S * S * 2 * C;
+    const int c0 = ch * N;
+    for (int p = pl; p < S * S; p += plane) {
+        const int y = p / S, x = p - y * S;
+        u32x4 oa = {0u, 0u, 0u, 0u}, ob = {0u, 0u, 0u, 0u};
+        if (x < gw) {
+            float a[N], o[N];
+            Vec<T>::unpack(ldg16(pbase + ((size_t)y * S + (y1 + x)) * C), a);
+            ob = ldg16(fbase + ((size_t)y * FW + (x1 + x)) * C);
+#pragma unroll
+            for (int j = 0; j < N; ++j) {
+                const int c = c0 + j;
+                o[j] = (a[j] - stat[c]) / stat[C + c] * stat[3 * C + c] + stat[2 * C + c];
+            }
+            oa = Vec<T>::pack(o);
+        }
+        stg16(obase + (size_t)p * 2 * C + c0, oa);
+        stg16(obase + (size_t)p * 2 * C + C + c0, ob);
+    }
+}
+
+extern "C" int mnet_adain_crop_concat(const void* prior, const void* feat, void* out, int32_t dtype, int32_t G,
+                                      int32_t S, int32_t C, int32_t feat_w, const int32_t* g_img,
+                                      const int32_t* g_x1, const int32_t* g_y1, const int32_t* g_w, void* stream) {
+    MNET_CHECK_ARG(prior && feat && out && g_img && g_x1 && g_y1 && g_w, "adain: null pointer");
+    MNET_CHECK_ARG(G > 0 && S > 0 && C > 0 && feat_w >= S, "adain: bad geometry");
+    MNET_CHECK_ARG(dtype == MNET_F32 || dtype == MNET_F16, "adain: bad dtype");
+    const int N = dtype == MNET_F16 ? 8 : 4;
+    MNET_CHECK_ALIGN(C % N == 0 && 256 % (C / N) == 0 && aligned16(prior) && aligned16(feat) && aligned16(out),
+                     "adain: C=%d unsupported or unaligned", C);
+    const size_t lds = (size_t)256 * N * 4 * sizeof(double) + (size_t)4 * C * sizeof(float);
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    if (dtype == MNET_F16) {
+        hipFuncSetAttribute(reinterpret_cast<const void*>(adain_crop_kernel<f16>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL(adain_crop_kernel<f16>, dim3(G), dim3(256), lds, st, (const f16*)prior, (const f16*)feat, (f16*)out, S, C, feat_w, g_img, g_x1, g_y1, g_w);
+    } else {
+        hipFuncSetAttribute(reinterpret_cast<const void*>(adain_crop_kernel<float>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL(adain_crop_kernel<float>, dim3(G), dim3(256), lds, st, (const float*)prior, (const float*)feat, (float*)out, S, C, feat_w, g_img, g_x1, g_y1, g_w);
+    }
+    MNET_LAUNCH_CHECK("adain_crop");
+    return MNET_OK;
+}
+
+// ============================================================================ ordered glyph scatter
+template <typename T>
+__global__ void __launch_bounds__(256) glyph_scatter_kernel(const T* __restrict__ feat, const T* __restrict__ scale,
+                                                            const T* __restrict__ shift, T* __restrict__ out,
+                                                            int S, int C, int FW, const int* __restrict__ g_start,
+                                                            const int* __restrict__ g_x1, const int* __restrict__ g_w,
+                                                            long long total_chunks) {
+    constexpr int N = Vec<T>::N;
+    const int cpp = C / N;
+    for (long long id = (long long)blockIdx.x * blockDim.x + threadIdx.x; id < total_chunks;
+         id += (long long)gridDim.x * blockDim.x) {
+        const int ch = (int)(id % cpp);
+        long long pix = id / cpp;
+        const int x = (int)(pix % FW); pix /= FW;
+        const int y = (int)(pix % S);
+        const int b = (int)(pix / S);
+        int owner = -1, ox = 0;
+        for (int gg = g_start[b + 1] - 1; gg >= g_start[b]; --gg) {      // last writer wins
+            const int x1 = g_x1[gg];
+            if (x >= x1 && x < x1 + g_w[gg]) { owner = gg; ox = x - x1; break; }
+        }
+        const u32x4 raw = ldg16(feat + (size_t)id * N);
+        if (owner < 0) { stg16(out + (size_t)id * N, raw); continue; }
+        float f[N], sc[N], sh[N], o[N];
+        Vec<T>::unpack(raw, f);
+        const size_t go = (((size_t)owner * S + y) * S + ox) * C + (size_t)ch * N;
+        Vec<T>::unpack(ldg16(scale + go), sc);
+        Vec<T>::unpack(ldg16(shift + go), sh);
+#pragma unroll
+        for (int j = 0; j < N; ++j) {
+            const float r = __fadd_rn(__fmul_rn(f[j], sc[j]), sh[j]);    // res = f*scale + shift  (:448)
+            o[j] = __fadd_rn(f[j], r);                                    // ori + res             (:449)
+        }
+        stg16(out + (size_t)id * N, Vec<T>::pack(o));
+    }
+}
+
+extern "C" int mnet_glyph_scatter_affine(const void* feat, const void* scale, const void* shift, void* out,
+                                         int32_t dtype, int32_t B, int32_t S, int32_t C, int32_t feat_w,
+                                         const int32_t* g_start, const int32_t* g_x1, const int32_t* g_w, void* stream) {
+    MNET_CHECK_ARG(feat && scale && shift && out && g_start && g_x1 && g_w, "scatter: null pointer");
+    MNET_CHECK_ARG(B > 0 && S > 0 && C > 0 && feat_w > 0, "scatter: bad geometry");
+    MNET_CHECK_ARG(dtype == MNET_F32 || dtype == MNET_F16, "scatter: bad dtype");
+    const int N = dtype == MNET_F16 ? 8 : 4;
+    MNET_CHECK_ALIGN(C % N == 0 && aligned16(feat) && aligned16(scale) && aligned16(shift) && aligned16(out),
+                     "scatter: unaligned");
+    const long long total = (long long)B * S * feat_w * (C / N);
+    const int blocks = (int)((total + 255) / 256 < 16384 ? (total + 255) / 256 : 16384);
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    if (dtype == MNET_F16) hipLaunchKernelGGL(glyph_scatter_kernel<f16>, dim3(blocks), dim3(256), 0, st, (const f16*)feat, (const f16*)scale, (const f16*)shift, (f16*)out, S, C, feat_w, g_start, g_x1, g_w, total);
+    else hipLaunchKernelGGL(glyph_scatter_kernel<float>, dim3(blocks), dim3(256), 0, st, (const float*)feat, (const float*)scale, (const float*)shift, (float*)out, S, C, feat_w, g_start, g_x1, g_w, total);
+    MNET_LAUNCH_CHECK("glyph_scatter");
+    return MNET_OK;
+}
+
+// ============================================================================ SelectText gather
+template <typename T>
+__global__ void __launch_bounds__(256) embed_gather_kernel(const float* __restrict__ emb, const int64_t* __restrict__ labels,
+                                                           T* __restrict__ out, int nc, int C, long long total_chunks) {
+    constexpr int N = Vec<T>::N;
+    const int cpp = C / N;
+    for (long long id = (long long)blockIdx.x * blockDim.x + threadIdx.x; id < total_chunks;
+         id += (long long)gridDim.x * blockDim.x) {
+        const int ch = (int)(id % cpp);
+        long long pix = id / cpp;                 // pixel in [N,4,4*nc]
+        const int x = (int)(pix % (4 * nc));
+        const int i = (int)(pix / (16 * nc));
+        const int64_t lab = labels[(size_t)i * nc + x / 4];
+        const float* e = emb + (size_t)lab * C + (size_t)ch * N;
+        float v[N];
+#pragma unroll
+        for (int j = 0; j < N; ++j) v[j] = e[j];
+        stg16(out + (size_t)id * N, Vec<T>::pack(v));
+    }
+}
+
+extern "C" int mnet_embed_gather(const float* emb, const int64_t* labels, void* out, int32_t dtype, int32_t N_,
+                                 int32_t nc, int32_t C, int32_t num_classes, void* stream) {
+    MNET_CHECK_ARG(emb && labels && out && N_ > 0 && nc > 0 && C > 0 && num_classes > 0, "embed_gather: bad args");
+    MNET_CHECK_ARG(dtype == MNET_F32 || dtype == MNET_F16, "embed_gather: bad dtype");
+    const int N = dtype == MNET_F16 ? 8 : 4;
+    MNET_CHECK_ALIGN(C % N == 0 && aligned16(out), "embed_gather: unaligned");
+    const long long total = (long long)N_ * 16 * nc * (C / N);
+    const int blocks = (int)((total + 255) / 256 < 16384 ? (total + 255) / 256 : 16384);
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    if (dtype == MNET_F16) hipLaunchKernelGGL(embed_gather_kernel<f16>, dim3(blocks), dim3(256), 0, st, emb, labels, (f16*)out, nc, C, total);
+    else hipLaunchKernelGGL(embed_gather_kernel<float>, dim3(blocks), dim3(256), 0, st, emb, labels, (float*)out, nc, C, total);
+    MNET_LAUNCH_CHECK("embed_gather");
+    return MNET_OK;
+}
+
+// ============================================================================ PixelNorm (one wave per row)
+__global__ void __launch_bounds__(256) pixelnorm_kernel(const float* __restrict__ x, float* __restrict__ y, int N_, int D) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (row >= N_) return;
+    const float* xr = x + (size_t)row * D;
+    float s = 0.f;
+    for (int i = lane; i < D; i += 64) s += xr[i] * xr[i];
+    s = wave_sum(s);
+    const float r = rsqrtf(s / (float)D + 1e-8f);
+    for (int i = lane; i < D; i += 64) y[(size_t)row * D + i] = xr[i] * r;
+}
+
+extern "C" int mnet_pixelnorm(const float* x, float* y, int32_t N_, int32_t D, void* stream) {
+    MNET_CHECK_ARG(x && y && N_ > 0 && D > 0, "pixelnorm: bad args");
+    hipLaunchKernelGGL(pixelnorm_kernel, dim3((N_ + 3) / 4), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), x, y, N_, D);
+    MNET_LAUNCH_CHECK("pixelnorm");
+    return MNET_OK;
+}
+
+// ============================================================================ demodulation
+// block per sample n: s^2 staged in LDS, thread o walks i with coalesced reads of wsq_t[i][o]
+__global__ void __launch_bounds__(256) demod_kernel(const float* __restrict__ style, const float* __restrict__ wsq_t,
+                                                    float* __restrict__ demod, int cin, int cout) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char dyn[];
+    float* s2 = reinterpret_cast<float*>(dyn);
+    const int n = blockIdx.x;
+    for (int i = threadIdx.x; i < cin; i += 256) { const float s = style[(size_t)n * cin + i]; s2[i] = s * s; }
+    __syncthreads();
+    for (int o = threadIdx.x; o < cout; o += 256) {
+        float acc = 0.f;
+        for (int i = 0; i < cin; ++i) acc = fmaf(s2[i], wsq_t[(size_t)i * cout + o], acc);
+        demod[(size_t)n * cout + o] = rsqrtf(acc + 1e-8f);
+    }
+}
+
+extern "C" int mnet_demod(const float* style, const float* wsq_t, float* demod, int32_t N_, int32_t cin,
+                          int32_t cout, void* stream) {
+    MNET_CHECK_ARG(style && wsq_t && demod && N_ > 0 && cin > 0 && cout > 0, "demod: bad args");
+    hipLaunchKernelGGL(demod_kernel, dim3(N_), dim3(256), (size_t)cin * sizeof(float), reinterpret_cast<hipStream_t>(stream),
+                       style, wsq_t, demod, cin, cout);
+    MNET_LAUNCH_CHECK("demod");
+    return MNET_OK;
+}

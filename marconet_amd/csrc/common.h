@@ -1,0 +1,88 @@
+// Shared device helpers for the gfx950 kernels of libmarconet_hip.so.  gfx950 only: wave = 64 lanes.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/marconet_hip.h"
+
+typedef _Float16 f16;
+typedef f16 f16x8 __attribute__((ext_vector_type(8)));
+typedef f16 f16x4 __attribute__((ext_vector_type(4)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));   // one raw 16-byte chunk
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+
+// host-side error plumbing (defined in api.hip)
+int mnet_fail(int code, const char* fmt, ...);
+
+#define MNET_CHECK_ARG(cond, ...) do { if (!(cond)) return mnet_fail(MNET_E_ARG, __VA_ARGS__); } while (0)
+#define MNET_CHECK_ALIGN(cond, ...) do { if (!(cond)) return mnet_fail(MNET_E_ALIGN, __VA_ARGS__); } while (0)
+#define MNET_LAUNCH_CHECK(what) do { hipError_t e__ = hipGetLastError(); \
+    if (e__ != hipSuccess) return mnet_fail(MNET_E_LAUNCH, "%s: %s", what, hipGetErrorString(e__)); } while (0)
+
+static inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+
+template <typename To, typename From>
+__device__ __forceinline__ To bitcast(const From& v) { return __builtin_bit_cast(To, v); }
+
+__device__ __forceinline__ u32x4 ldg16(const void* p) { return *reinterpret_cast<const u32x4*>(p); }
+__device__ __forceinline__ void stg16(void* p, u32x4 v) { *reinterpret_cast<u32x4*>(p) = v; }
+
+// number of elements in a 16-byte chunk
+template <typename T> struct ChunkOf { static constexpr int N = 16 / sizeof(T); };
+
+// unpack a 16-byte chunk to fp32 lanes and back (f16: 8 values, f32: 4 values)
+template <typename T> struct Vec;
+template <> struct Vec<float> {
+    static constexpr int N = 4;
+    static __device__ __forceinline__ void unpack(u32x4 raw, float* o) {
+        f32x4 v = bitcast<f32x4>(raw); o[0] = v[0]; o[1] = v[1]; o[2] = v[2]; o[3] = v[3];
+    }
+    static __device__ __forceinline__ u32x4 pack(const float* o) {
+        f32x4 v = {o[0], o[1], o[2], o[3]}; return bitcast<u32x4>(v);
+    }
+};
+template <> struct Vec<f16> {
+    static constexpr int N = 8;
+    static __device__ __forceinline__ void unpack(u32x4 raw, float* o) {
+        f16x8 v = bitcast<f16x8>(raw);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o[j] = (float)v[j];
+    }
+    static __device__ __forceinline__ u32x4 pack(const float* o) {
+        f16x8 v;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = (f16)o[j];
+        return bitcast<u32x4>(v);
+    }
+};
+
+__device__ __forceinline__ float act_apply(float v, int act) {
+    switch (act) {
+        case MNET_ACT_RELU: return fmaxf(v, 0.f);
+        case MNET_ACT_LRELU: return v > 0.f ? v : v * 0.2f;
+        case MNET_ACT_LRELU_SQRT2: return (v > 0.f ? v : v * 0.2f) * 1.41421356237309515f;
+        case MNET_ACT_TANH: return tanhf(v);
+        case MNET_ACT_GELU: return 0.5f * v * (1.f + erff(v * 0.70710678118654752f));
+        case MNET_ACT_SIGMOID: return 1.f / (1.f + expf(-v));
+        default: return v;
+    }
+}
+
+__device__ __forceinline__ float swish_f(float v) { return v / (1.f + expf(-v)); }
+
+// 64-lane butterfly reductions
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ double wave_sum_d(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}

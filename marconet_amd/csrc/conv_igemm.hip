@@ -1,0 +1,319 @@
+// Implicit-GEMM convolution for gfx950 (MI355X, CDNA4) — the kernel that carries >95 % of the FLOPs of
+// the MARCONet forward.
+//
+// GEMM view (computed transposed so that every lane ends up owning 4 *consecutive output channels*
+// of one pixel, which makes bias / demod / residual loads and the NHWC store 8- or 16-byte vector ops):
+//     D[cout][pixel] = sum_k  W[cout][k] * X[pixel][k],     k = (r, s, cin)  — NHWC makes cin contiguous
+//   MFMA A operand = weight fragment (16 cout x K), B operand = activation fragment (K x 16 pixels),
+//   v_mfma_f32_16x16x32_f16 (f16 storage, fp32 accumulate) or v_mfma_f32_16x16x4_f32 (exact fp32).
+//
+// Tiling: one 256-thread workgroup (4 waves) computes a BC(cout) x BP(pixel) tile; K is walked in
+// 128-byte slabs (64 halves / 32 floats).  Both operands are staged through LDS as [rows][128 B] with a
+// 16-byte-chunk XOR swizzle (chunk ^= (row>>1)&7) so that the ds_read_b128 fragment reads — 16 rows at
+// one logical chunk per lane group — hit 16 distinct 16-byte slots of the 256-byte bank row, and the
+// ds_write_b128 staging writes (8 consecutive lanes = one 128-byte row) stay conflict-free too.
+// Global->register loads of slab t+1 are issued before the MFMAs of slab t (register prefetch), the
+// LDS is double-buffered, one barrier per slab.  The input-side transforms (modulation scale,
+// GroupNorm affine + swish, zero padding, ragged valid width, channel concat) run on the staged
+// registers between the global load and the LDS write, so they cost no extra HBM pass.
+// Workgroup ids are remapped so that each XCD (private 4 MiB L2) owns a contiguous run of tiles and the
+// cout-tiles of one pixel tile are neighbours (the activation slab is then re-read from L2, not HBM).
+#include "common.h"
+
+struct ConvArgs {
+    const void* x0; const void* x1; const void* wgt; void* y; const void* res;
+    const float* in_scale; const float* in_shift; const float* out_scale; const float* bias;
+    const int* valid_w;
+    int c0, c1, cin;
+    int n, h, w, ho, wo, cout;
+    int kh, kw, sh, sw, ph, pw;
+    int K, npix, howo;
+    int in_swish, act, res_mod;
+    int ktiles, tilesC;
+};
+
+template <typename T> struct Mma;
+template <> struct Mma<f16> {
+    static __device__ __forceinline__ void run(f32x4& acc, const u32x4& a, const u32x4& b) {
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(bitcast<f16x8>(a), bitcast<f16x8>(b), acc, 0, 0, 0);
+    }
+};
+template <> struct Mma<float> {
+    // lane (l16, g) holds k = 4g..4g+3 of a 16-wide k-step; MFMA j consumes component j of A and B:
+    // the k permutation is the same on both operands, so the dot product is unchanged.
+    static __device__ __forceinline__ void run(f32x4& acc, const u32x4& a, const u32x4& b) {
+        const f32x4 af = bitcast<f32x4>(a), bf = bitcast<f32x4>(b);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(af[0], bf[0], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(af[1], bf[1], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(af[2], bf[2], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(af[3], bf[3], acc, 0, 0, 0);
+    }
+};
+
+__device__ __forceinline__ int swz(int row, int chunk) { return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4); }
+
+template <typename T>
+__device__ __forceinline__ u32x4 in_transform(u32x4 raw, const float* sc, const float* sh, bool swish) {
+    constexpr int N = Vec<T>::N;
+    float v[N];
+    Vec<T>::unpack(raw, v);
+#pragma unroll
+    for (int j = 0; j < N; j += 4) {
+        const f32x4 s4 = *reinterpret_cast<const f32x4*>(sc + j);
+        f32x4 b4 = {0.f, 0.f, 0.f, 0.f};
+        if (sh) b4 = *reinterpret_cast<const f32x4*>(sh + j);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            float t = v[j + q] * s4[q] + b4[q];
+            if (swish) t = t * (1.f / (1.f + expf(-t)));
+            v[j + q] = t;
+        }
+    }
+    return Vec<T>::pack(v);
+}
+
+template <typename T, int BC, int BP, int WC, int WP>
+__global__ void __launch_bounds__(256, 2) conv_igemm_kernel(const ConvArgs p) {
+    constexpr int KCH = 16 / (int)sizeof(T);      // elements per 16-byte chunk
+    constexpr int BK = 8 * KCH;                   // elements per 128-byte k-slab
+    constexpr int FC = BC / WC / 16, FP = BP / WP / 16;
+    constexpr int WROWS = (BC + 31) / 32;         // staged chunks per thread, weight tile
+    constexpr int XROWS = BP / 32;                // staged chunks per thread, activation tile
+    constexpr int STAGE = (BC + BP) * 128;
+    static_assert(WC * WP == 4, "4 waves");
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wc = wave / WP, wp = wave % WP;
+    const int l16 = lane & 15, g = lane >> 4;
+
+    // ---- XCD-aware, bijective tile remap: XCD x (= blockIdx % 8) owns a contiguous run of tiles
+    const int nwg = gridDim.x, bid = blockIdx.x;
+    const int q8 = nwg >> 3, r8 = nwg & 7, xcd = bid & 7;
+    const int wg = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
+    const int tc = wg % p.tilesC, tp = wg / p.tilesC;
+    const int co0 = tc * BC, pix0 = tp * BP;
+
+    const int cc = tid & 7;          // chunk column inside the 128-byte slab
+    const int r0 = tid >> 3;         // first staged row (0..31); further rows at +32
+
+    // ---- per-thread geometry of the staged activation rows (fixed over the K loop)
+    int xn[XROWS], xih[XROWS], xiw[XROWS], xvw[XROWS];
+#pragma unroll
+    for (int i = 0; i < XROWS; ++i) {
+        const int pix = pix0 + r0 + 32 * i;
+        if (pix < p.npix) {
+            const int n = pix / p.howo, rem = pix - n * p.howo;
+            const int oh = rem / p.wo, ow = rem - oh * p.wo;
+            xn[i] = n; xih[i] = oh * p.sh - p.ph; xiw[i] = ow * p.sw - p.pw;
+            xvw[i] = p.valid_w ? min(p.valid_w[n], p.w) : p.w;
+        } else { xn[i] = -1; xih[i] = 0; xiw[i] = 0; xvw[i] = 0; }
+    }
+
+    u32x4 wreg[WROWS], xreg[XROWS];
+    int xc = 0;             // input channel of this thread's chunk in the slab being staged
+    unsigned xok = 0;       // per-row validity bits of the slab being staged
+    const u32x4 zero4 = {0u, 0u, 0u, 0u};
+
+    auto load_slab = [&](int kt) {
+        const int k0 = kt * BK;                       // wave-uniform
+        const int tap0 = k0 / p.cin;                  // wave-uniform division (scalar unit)
+        int c = k0 - tap0 * p.cin + cc * KCH;
+        int fr = tap0 / p.kw, fs = tap0 - fr * p.kw;
+        while (c >= p.cin) { c -= p.cin; if (++fs == p.kw) { fs = 0; ++fr; } }
+        const int k = k0 + cc * KCH;
+        const bool kok = k < p.K;
+        // weights
+#pragma unroll
+        for (int i = 0; i < WROWS; ++i) {
+            const int row = r0 + 32 * i, co = co0 + row;
+            const bool ok = kok && row < BC && co < p.cout;
+            wreg[i] = ok ? ldg16(reinterpret_cast<const T*>(p.wgt) + (size_t)co * p.K + k) : zero4;
+        }
+        // activations (implicit im2col gather; channel concat of two sources)
+        const T* src; int cs, cl;
+        if (c < p.c0) { src = reinterpret_cast<const T*>(p.x0); cs = p.c0; cl = c; }
+        else { src = reinterpret_cast<const T*>(p.x1); cs = p.c1; cl = c - p.c0; }
+        xc = c; xok = 0;
+#pragma unroll
+        for (int i = 0; i < XROWS; ++i) {
+            const int ih = xih[i] + fr, iw = xiw[i] + fs;
+            const bool ok = kok && xn[i] >= 0 && (unsigned)ih < (unsigned)p.h && (unsigned)iw < (unsigned)xvw[i];
+            xreg[i] = ok ? ldg16(src + ((size_t)(xn[i] * p.h + ih) * p.w + iw) * cs + cl) : zero4;
+            xok |= (ok ? 1u : 0u) << i;
+        }
+    };
+
+    auto store_slab = [&](int stage) {
+        unsigned char* sw_ = smem + stage * STAGE;
+        unsigned char* sx_ = sw_ + BC * 128;
+#pragma unroll
+        for (int i = 0; i < WROWS; ++i) {
+            const int row = r0 + 32 * i;
+            if (row < BC) stg16(sw_ + swz(row, cc), wreg[i]);
+        }
+#pragma unroll
+        for (int i = 0; i < XROWS; ++i) {
+            const int row = r0 + 32 * i;
+            u32x4 v = xreg[i];
+            if (p.in_scale && ((xok >> i) & 1u)) {
+                const size_t o = (size_t)xn[i] * p.cin + xc;
+                v = in_transform<T>(v, p.in_scale + o, p.in_shift ? p.in_shift + o : nullptr, p.in_swish != 0);
+            }
+            stg16(sx_ + swz(row, cc), v);
+        }
+    };
+
+    f32x4 acc[FC][FP];
+#pragma unroll
+    for (int a = 0; a < FC; ++a)
+#pragma unroll
+        for (int b = 0; b < FP; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    auto compute_slab = [&](int stage) {
+        const unsigned char* sw_ = smem + stage * STAGE;
+        const unsigned char* sx_ = sw_ + BC * 128;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            const int chunk = ks * 4 + g;
+            u32x4 a[FC], b[FP];
+#pragma unroll
+            for (int f = 0; f < FC; ++f) {
+                const int row = wc * (BC / WC) + f * 16 + l16;
+                a[f] = *reinterpret_cast<const u32x4*>(sw_ + swz(row, chunk));
+            }
+#pragma unroll
+            for (int f = 0; f < FP; ++f) {
+                const int row = wp * (BP / WP) + f * 16 + l16;
+                b[f] = *reinterpret_cast<const u32x4*>(sx_ + swz(row, chunk));
+            }
+#pragma unroll
+            for (int fa = 0; fa < FC; ++fa)
+#pragma unroll
+                for (int fb = 0; fb < FP; ++fb) Mma<T>::run(acc[fa][fb], a[fa], b[fb]);
+        }
+    };
+
+    // ---- main loop: register prefetch of slab t+1 over the MFMAs of slab t, double-buffered LDS
+    load_slab(0);
+    store_slab(0);
+    __syncthreads();
+    for (int kt = 0; kt < p.ktiles; ++kt) {
+        const bool more = kt + 1 < p.ktiles;
+        if (more) load_slab(kt + 1);
+        compute_slab(kt & 1);
+        if (more) store_slab((kt + 1) & 1);
+        __syncthreads();
+    }
+
+    // ---- epilogue: lane owns channels co..co+3 of one pixel per fragment
+    T* yo = reinterpret_cast<T*>(p.y);
+    const T* rs = reinterpret_cast<const T*>(p.res);
+#pragma unroll
+    for (int fb = 0; fb < FP; ++fb) {
+        const int pix = pix0 + wp * (BP / WP) + fb * 16 + l16;
+        if (pix >= p.npix) continue;
+        const int n = p.out_scale ? pix / p.howo : 0;
+        const int rpix = p.res_mod > 0 ? pix % p.res_mod : pix;
+#pragma unroll
+        for (int fa = 0; fa < FC; ++fa) {
+            const int co = co0 + wc * (BC / WC) + fa * 16 + g * 4;
+            if (co >= p.cout) continue;
+            f32x4 v = acc[fa][fb];
+            if (p.out_scale) v *= *reinterpret_cast<const f32x4*>(p.out_scale + (size_t)n * p.cout + co);
+            if (p.bias) v += *reinterpret_cast<const f32x4*>(p.bias + co);
+            if (rs) {
+                const T* rp = rs + (size_t)rpix * p.cout + co;
+                if constexpr (sizeof(T) == 4) {
+                    v += *reinterpret_cast<const f32x4*>(rp);
+                } else {
+                    const f16x4 r4 = *reinterpret_cast<const f16x4*>(rp);
+                    v[0] += (float)r4[0]; v[1] += (float)r4[1]; v[2] += (float)r4[2]; v[3] += (float)r4[3];
+                }
+            }
+            if (p.act != MNET_ACT_NONE) {
+                v[0] = act_apply(v[0], p.act); v[1] = act_apply(v[1], p.act);
+                v[2] = act_apply(v[2], p.act); v[3] = act_apply(v[3], p.act);
+            }
+            T* yp = yo + (size_t)pix * p.cout + co;
+            if constexpr (sizeof(T) == 4) {
+                *reinterpret_cast<f32x4*>(yp) = v;
+            } else {
+                const f16x4 o4 = {(f16)v[0], (f16)v[1], (f16)v[2], (f16)v[3]};
+                *reinterpret_cast<f16x4*>(yp) = o4;
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ host
+template <typename T, int BC, int BP, int WC, int WP>
+static int launch_cfg(const ConvArgs& a, hipStream_t st) {
+    constexpr int LDS = 2 * (BC + BP) * 128;
+    auto kern = conv_igemm_kernel<T, BC, BP, WC, WP>;
+    static thread_local bool attr_set = false;   // per instantiation, per thread: idempotent and cheap
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+        if (e != hipSuccess) return mnet_fail(MNET_E_LAUNCH, "hipFuncSetAttribute: %s", hipGetErrorString(e));
+        attr_set = true;
+    }
+    ConvArgs b = a;
+    b.tilesC = (a.cout + BC - 1) / BC;
+    const int tilesP = (a.npix + BP - 1) / BP;
+    hipLaunchKernelGGL(kern, dim3((unsigned)(b.tilesC * tilesP)), dim3(256), LDS, st, b);
+    MNET_LAUNCH_CHECK("conv_igemm_kernel");
+    return MNET_OK;
+}
+
+template <typename T>
+static int launch_dtype(const ConvArgs& a, hipStream_t st) {
+    if (a.cout >= 128) return launch_cfg<T, 128, 128, 2, 2>(a, st);
+    if (a.cout >= 64) return launch_cfg<T, 64, 128, 2, 2>(a, st);
+    if (a.cout >= 32) return launch_cfg<T, 32, 128, 1, 4>(a, st);
+    return launch_cfg<T, 16, 128, 1, 4>(a, st);
+}
+
+extern "C" double mnet_conv2d_flops(const mnet_conv_desc* d) {
+    if (!d) return 0.0;
+    return 2.0 * (double)d->n * d->ho * d->wo * d->cout * (double)d->kh * d->kw * (d->c0 + d->c1);
+}
+
+extern "C" int mnet_conv2d_nhwc(const mnet_conv_desc* d, void* stream) {
+    MNET_CHECK_ARG(d != nullptr, "conv: null descriptor");
+    MNET_CHECK_ARG(d->dtype == MNET_F32 || d->dtype == MNET_F16, "conv: bad dtype %d", d->dtype);
+    MNET_CHECK_ARG(d->x0 && d->wgt && d->y, "conv: null tensor pointer");
+    MNET_CHECK_ARG(d->n > 0 && d->h > 0 && d->w > 0 && d->ho > 0 && d->wo > 0, "conv: bad geometry");
+    MNET_CHECK_ARG(d->c0 > 0 && d->c1 >= 0 && d->cout > 0, "conv: bad channel counts");
+    MNET_CHECK_ARG((d->c1 == 0) == (d->x1 == nullptr), "conv: x1/c1 mismatch");
+    MNET_CHECK_ARG(d->kh > 0 && d->kw > 0 && d->stride_h > 0 && d->stride_w > 0 && d->pad_h >= 0 && d->pad_w >= 0,
+                   "conv: bad filter geometry");
+    MNET_CHECK_ARG(d->ho == (d->h + 2 * d->pad_h - d->kh) / d->stride_h + 1 &&
+                   d->wo == (d->w + 2 * d->pad_w - d->kw) / d->stride_w + 1 &&
+                   d->h + 2 * d->pad_h >= d->kh && d->w + 2 * d->pad_w >= d->kw,
+                   "conv: ho/wo (%d,%d) inconsistent with h,w,k,stride,pad", d->ho, d->wo);
+    MNET_CHECK_ARG(d->act >= MNET_ACT_NONE && d->act <= MNET_ACT_SIGMOID, "conv: bad act %d", d->act);
+    MNET_CHECK_ARG(!(d->in_shift || d->in_swish) || d->in_scale, "conv: in_shift/in_swish need in_scale");
+    MNET_CHECK_ARG(d->res_mod >= 0, "conv: res_mod < 0");
+    MNET_CHECK_ALIGN(d->c0 % 8 == 0 && d->c1 % 8 == 0, "conv: c0=%d c1=%d must be multiples of 8", d->c0, d->c1);
+    MNET_CHECK_ALIGN(d->cout % 4 == 0, "conv: cout=%d must be a multiple of 4", d->cout);
+    MNET_CHECK_ALIGN(aligned16(d->x0) && aligned16(d->x1) && aligned16(d->wgt) && aligned16(d->y) &&
+                     aligned16(d->residual) && aligned16(d->in_scale) && aligned16(d->in_shift) &&
+                     aligned16(d->out_scale) && aligned16(d->bias), "conv: pointers must be 16-byte aligned");
+    const long long npix = (long long)d->n * d->ho * d->wo;
+    MNET_CHECK_ARG(npix < (1ll << 31) && (long long)d->n * d->h * d->w < (1ll << 31), "conv: too many pixels");
+
+    ConvArgs a;
+    a.x0 = d->x0; a.x1 = d->x1; a.wgt = d->wgt; a.y = d->y; a.res = d->residual;
+    a.in_scale = d->in_scale; a.in_shift = d->in_shift; a.out_scale = d->out_scale; a.bias = d->bias;
+    a.valid_w = d->valid_w;
+    a.c0 = d->c0; a.c1 = d->c1; a.cin = d->c0 + d->c1;
+    a.n = d->n; a.h = d->h; a.w = d->w; a.ho = d->ho; a.wo = d->wo; a.cout = d->cout;
+    a.kh = d->kh; a.kw = d->kw; a.sh = d->stride_h; a.sw = d->stride_w; a.ph = d->pad_h; a.pw = d->pad_w;
+    a.K = d->kh * d->kw * a.cin; a.npix = (int)npix; a.howo = d->ho * d->wo;
+    a.in_swish = d->in_swish; a.act = d->act; a.res_mod = d->res_mod;
+    const int bk = d->dtype == MNET_F16 ? 64 : 32;
+    a.ktiles = (a.K + bk - 1) / bk; a.tilesC = 0;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    return d->dtype == MNET_F16 ? launch_dtype<f16>(a, st) : launch_dtype<float>(a, st);
+}
