@@ -175,6 +175,16 @@ int mnet_demod(const float* style, const float* wsq_t, float* demod, int32_t N, 
 /* argmax over the last dim (first maximal index, like torch.max(...,1)[1] in test_w.py:36) */
 int mnet_argmax_rows(const float* x, int64_t* idx, int32_t rows, int32_t d, void* stream);
 
+/* flat dtype conversion (count % 4 == 0), used where the fp16 conv stack hands over to the fp32 ViT */
+int mnet_convert(const void* src, int32_t src_dtype, void* dst, int32_t dst_dtype, int64_t count, void* stream);
+
+/* K5 standalone: the operator boundary the reference itself has — basicsr.ops.fused_act.fused_leaky_relu
+ * (models/networks.py:10,195,241): y = scale * leaky_relu(x + bias[(i/inner) % C], negative_slope) on a
+ * contiguous fp32 tensor viewed as [outer, C, inner].  bias may be NULL.  (On the hot path this math is
+ * fused into mnet_conv2d_nhwc's epilogue.) */
+int mnet_fused_bias_act(const float* x, const float* bias, float* y, int64_t total, int32_t C, int32_t inner,
+                        float negative_slope, float scale, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

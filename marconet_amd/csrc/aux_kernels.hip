@@ -437,3 +437,54 @@ extern "C" int mnet_demod(const float* style, const float* wsq_t, float* demod, 
     MNET_LAUNCH_CHECK("demod");
     return MNET_OK;
 }
+
+// ============================================================================ dtype conversion (flat)
+template <typename S, typename D>
+__global__ void __launch_bounds__(256) convert_kernel(const S* __restrict__ src, D* __restrict__ dst, long long n4) {
+    // 4 elements per thread-iteration
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long long)gridDim.x * blockDim.x) {
+        const S* s = src + i * 4; D* d = dst + i * 4;
+        const float a = (float)s[0], b = (float)s[1], c = (float)s[2], e = (float)s[3];
+        d[0] = (D)a; d[1] = (D)b; d[2] = (D)c; d[3] = (D)e;
+    }
+}
+
+extern "C" int mnet_convert(const void* src, int32_t src_dtype, void* dst, int32_t dst_dtype, int64_t count, void* stream) {
+    MNET_CHECK_ARG(src && dst && count > 0 && count % 4 == 0, "convert: bad args (count %% 4 == 0)");
+    MNET_CHECK_ARG((src_dtype == MNET_F32 || src_dtype == MNET_F16) && (dst_dtype == MNET_F32 || dst_dtype == MNET_F16), "convert: bad dtype");
+    const long long n4 = count / 4;
+    const int blocks = (int)((n4 + 255) / 256 < 16384 ? (n4 + 255) / 256 : 16384);
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    if (src_dtype == MNET_F16 && dst_dtype == MNET_F32) hipLaunchKernelGGL((convert_kernel<f16, float>), dim3(blocks), dim3(256), 0, st, (const f16*)src, (float*)dst, n4);
+    else if (src_dtype == MNET_F32 && dst_dtype == MNET_F16) hipLaunchKernelGGL((convert_kernel<float, f16>), dim3(blocks), dim3(256), 0, st, (const float*)src, (f16*)dst, n4);
+    else if (src_dtype == MNET_F32) hipLaunchKernelGGL((convert_kernel<float, float>), dim3(blocks), dim3(256), 0, st, (const float*)src, (float*)dst, n4);
+    else hipLaunchKernelGGL((convert_kernel<f16, f16>), dim3(blocks), dim3(256), 0, st, (const f16*)src, (f16*)dst, n4);
+    MNET_LAUNCH_CHECK("convert");
+    return MNET_OK;
+}
+
+// ============================================================================ fused bias + LeakyReLU (standalone op)
+// The operator boundary the reference already has: basicsr.ops.fused_act.fused_leaky_relu(input, bias, 0.2, sqrt2)
+// on a contiguous fp32 [N,C,inner] tensor (upstream kernel: x += b[(i/inner) % C]; y = x>0?x:alpha*x; out = y*scale).
+// On the hot path this math lives in the conv epilogue; this entry point exists so that
+// `from basicsr.ops.fused_act import fused_leaky_relu, FusedLeakyReLU` can be served without basicsr.
+__global__ void __launch_bounds__(256) fused_bias_act_kernel(const float* __restrict__ x, const float* __restrict__ bias,
+                                                             float* __restrict__ y, long long total, int C, int inner,
+                                                             float slope, float scale) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        float v = x[i];
+        if (bias) v += bias[(i / inner) % C];
+        v = v > 0.f ? v : v * slope;
+        y[i] = v * scale;
+    }
+}
+
+extern "C" int mnet_fused_bias_act(const float* x, const float* bias, float* y, int64_t total, int32_t C, int32_t inner,
+                                   float negative_slope, float scale, void* stream) {
+    MNET_CHECK_ARG(x && y && total > 0 && C > 0 && inner > 0, "fused_bias_act: bad args");
+    const int blocks = (int)((total + 255) / 256 < 16384 ? (total + 255) / 256 : 16384);
+    hipLaunchKernelGGL(fused_bias_act_kernel, dim3(blocks), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), x, bias, y,
+                       (long long)total, C, inner, negative_slope, scale);
+    MNET_LAUNCH_CHECK("fused_bias_act");
+    return MNET_OK;
+}

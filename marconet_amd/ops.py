@@ -1,0 +1,286 @@
+"""Tensor-level wrappers over the C-ABI.  PyTorch is plumbing only: it owns the device memory
+(caching allocator) and the current HIP stream; every arithmetic op below is a hand-written gfx950 kernel.
+
+Activations are NHWC torch tensors of dtype float32 or float16, shape [N,H,W,C].
+"""
+import ctypes
+
+import torch
+
+from . import _lib
+from ._lib import (ACT_GELU, ACT_LRELU, ACT_LRELU_SQRT2, ACT_NONE, ACT_RELU, ACT_SIGMOID, ACT_TANH, MNET_F16,
+                   MNET_F32, ConvDesc)
+
+__all__ = ["conv2d", "linear", "nchw_to_nhwc", "nhwc_to_nchw", "upsample2x", "groupnorm_affine",
+           "adain_crop_concat", "glyph_scatter_affine", "layernorm", "token_mix", "attention", "pixelnorm",
+           "embed_gather", "demod", "argmax_rows", "convert", "fused_bias_act", "stats",
+           "ACT_NONE", "ACT_RELU", "ACT_LRELU", "ACT_LRELU_SQRT2", "ACT_TANH", "ACT_GELU", "ACT_SIGMOID"]
+
+
+def _dt(t):
+    if t.dtype == torch.float32:
+        return MNET_F32
+    if t.dtype == torch.float16:
+        return MNET_F16
+    raise TypeError("marconet_amd: unsupported dtype %s" % t.dtype)
+
+
+def _p(t):
+    return None if t is None else ctypes.c_void_p(t.data_ptr())
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _need_cuda(*ts):
+    for t in ts:
+        if t is not None and not t.is_cuda:
+            raise RuntimeError("marconet_amd: tensors must live on a HIP device (got %s); there is no CPU path" % t.device)
+        if t is not None and not t.is_contiguous():
+            raise RuntimeError("marconet_amd: non-contiguous tensor passed to a kernel wrapper")
+
+
+class _Stats:
+    """Optional accounting for bench.py: algorithmic FLOPs and per-launch HIP-event timing of the conv kernel."""
+
+    def __init__(self):
+        self.enabled = False
+        self.timing = False
+        self.reset()
+
+    def reset(self):
+        self.conv_flops = 0.0
+        self.conv_launches = 0
+        self.events = []       # (start, end, flops, dtype)
+
+    def conv_time_ms(self):
+        return sum(s.elapsed_time(e) for s, e, _, _ in self.events)
+
+
+stats = _Stats()
+
+
+def conv2d(x0, wgt, cout, kh=1, kw=1, stride=(1, 1), pad=(0, 0), x1=None, in_scale=None, in_shift=None,
+           in_swish=False, valid_w=None, out_scale=None, bias=None, residual=None, res_mod=0, act=ACT_NONE,
+           out=None):
+    """mnet_conv2d_nhwc.  x0 [N,H,W,C0] (+ optional x1 [N,H,W,C1]); wgt packed [cout,kh,kw,C0+C1] same dtype."""
+    lib = _lib.load()
+    _need_cuda(x0, x1, wgt, in_scale, in_shift, valid_w, out_scale, bias, residual, out)
+    n, h, w, c0 = x0.shape
+    c1 = 0 if x1 is None else x1.shape[3]
+    if wgt.dtype != x0.dtype or wgt.numel() != cout * kh * kw * (c0 + c1):
+        raise RuntimeError("conv2d: weight dtype/shape mismatch (%s %s vs cout=%d k=%dx%d cin=%d)"
+                           % (wgt.dtype, tuple(wgt.shape), cout, kh, kw, c0 + c1))
+    ho = (h + 2 * pad[0] - kh) // stride[0] + 1
+    wo = (w + 2 * pad[1] - kw) // stride[1] + 1
+    if out is None:
+        out = torch.empty((n, ho, wo, cout), dtype=x0.dtype, device=x0.device)
+    d = ConvDesc()
+    d.dtype = _dt(x0)
+    d.x0, d.c0 = x0.data_ptr(), c0
+    d.x1, d.c1 = (None if x1 is None else x1.data_ptr()), c1
+    d.n, d.h, d.w = n, h, w
+    d.wgt = wgt.data_ptr()
+    d.cout, d.kh, d.kw = cout, kh, kw
+    d.stride_h, d.stride_w, d.pad_h, d.pad_w = stride[0], stride[1], pad[0], pad[1]
+    d.ho, d.wo = ho, wo
+    d.in_scale = None if in_scale is None else in_scale.data_ptr()
+    d.in_shift = None if in_shift is None else in_shift.data_ptr()
+    d.in_swish = 1 if in_swish else 0
+    d.valid_w = None if valid_w is None else valid_w.data_ptr()
+    d.out_scale = None if out_scale is None else out_scale.data_ptr()
+    d.bias = None if bias is None else bias.data_ptr()
+    d.residual = None if residual is None else residual.data_ptr()
+    d.res_mod = res_mod
+    d.act = act
+    d.y = out.data_ptr()
+    for t, nm in ((in_scale, "in_scale"), (in_shift, "in_shift"), (out_scale, "out_scale"), (bias, "bias")):
+        if t is not None and t.dtype != torch.float32:
+            raise TypeError("conv2d: %s must be float32" % nm)
+    if valid_w is not None and valid_w.dtype != torch.int32:
+        raise TypeError("conv2d: valid_w must be int32")
+    if residual is not None and residual.dtype != x0.dtype:
+        raise TypeError("conv2d: residual dtype mismatch")
+    if stats.enabled:
+        fl = lib.mnet_conv2d_flops(ctypes.byref(d))
+        stats.conv_flops += fl
+        stats.conv_launches += 1
+        if stats.timing:
+            s = torch.cuda.Event(enable_timing=True)
+            e = torch.cuda.Event(enable_timing=True)
+            s.record()
+            _lib.check(lib.mnet_conv2d_nhwc(ctypes.byref(d), _stream()), "mnet_conv2d_nhwc")
+            e.record()
+            stats.events.append((s, e, fl, d.dtype))
+            return out
+    _lib.check(lib.mnet_conv2d_nhwc(ctypes.byref(d), _stream()), "mnet_conv2d_nhwc")
+    return out
+
+
+def linear(x, wgt, out_features, bias=None, act=ACT_NONE, residual=None, res_mod=0):
+    """nn.Linear as a 1x1 conv over a [1,1,M,K] map: x [M,K] → [M,out_features]."""
+    m, k = x.shape
+    r = None if residual is None else residual.reshape(1, 1, -1, out_features)
+    y = conv2d(x.reshape(1, 1, m, k), wgt, out_features, bias=bias, act=act, residual=r, res_mod=res_mod)
+    return y.reshape(m, out_features)
+
+
+def nchw_to_nhwc(src, dtype, c_ld=None):
+    lib = _lib.load()
+    _need_cuda(src)
+    if src.dtype != torch.float32:
+        raise TypeError("nchw_to_nhwc: fp32 NCHW input expected (the reference's tensors are fp32)")
+    n, c, h, w = src.shape
+    c_ld = c_ld or c
+    dst = torch.empty((n, h, w, c_ld), dtype=dtype, device=src.device)
+    _lib.check(lib.mnet_nchw_to_nhwc(_p(src), _p(dst), _dt(dst), n, c, h, w, c_ld, _stream()), "mnet_nchw_to_nhwc")
+    return dst
+
+
+def nhwc_to_nchw(src, c=None):
+    lib = _lib.load()
+    _need_cuda(src)
+    n, h, w, c_ld = src.shape
+    c = c or c_ld
+    dst = torch.empty((n, c, h, w), dtype=torch.float32, device=src.device)
+    _lib.check(lib.mnet_nhwc_to_nchw(_p(src), _dt(src), _p(dst), n, c, h, w, c_ld, _stream()), "mnet_nhwc_to_nchw")
+    return dst
+
+
+def upsample2x(src):
+    lib = _lib.load()
+    _need_cuda(src)
+    n, h, w, c = src.shape
+    dst = torch.empty((n, 2 * h, 2 * w, c), dtype=src.dtype, device=src.device)
+    _lib.check(lib.mnet_upsample2x_nhwc(_p(src), _p(dst), _dt(src), n, h, w, c, _stream()), "mnet_upsample2x_nhwc")
+    return dst
+
+
+def groupnorm_affine(x, gamma, beta, eps=1e-6, valid_w=None):
+    """→ (scale [N,C], shift [N,C]) fp32 for conv2d(in_scale=, in_shift=, in_swish=True)."""
+    lib = _lib.load()
+    _need_cuda(x, gamma, beta, valid_w)
+    n, h, w, c = x.shape
+    slices = max(1, min(128, (h * w) // 2048))
+    partial = torch.empty((n * slices * (c // 32) * 2,), dtype=torch.float64, device=x.device)
+    scale = torch.empty((n, c), dtype=torch.float32, device=x.device)
+    shift = torch.empty((n, c), dtype=torch.float32, device=x.device)
+    _lib.check(lib.mnet_groupnorm_affine(_p(x), _dt(x), n, h, w, c, _p(valid_w), _p(gamma), _p(beta), eps,
+                                         _p(partial), slices, _p(scale), _p(shift), _stream()), "mnet_groupnorm_affine")
+    return scale, shift
+
+
+def adain_crop_concat(prior, feat, g_img, g_x1, g_y1, g_w):
+    lib = _lib.load()
+    _need_cuda(prior, feat, g_img, g_x1, g_y1, g_w)
+    G, S, S2, C = prior.shape
+    B, FH, FW, FC = feat.shape
+    if S != S2 or FH != S or FC != C or prior.dtype != feat.dtype:
+        raise RuntimeError("adain_crop_concat: shape mismatch prior %s feat %s" % (tuple(prior.shape), tuple(feat.shape)))
+    out = torch.empty((G, S, S, 2 * C), dtype=prior.dtype, device=prior.device)
+    _lib.check(lib.mnet_adain_crop_concat(_p(prior), _p(feat), _p(out), _dt(prior), G, S, C, FW, _p(g_img), _p(g_x1),
+                                          _p(g_y1), _p(g_w), _stream()), "mnet_adain_crop_concat")
+    return out
+
+
+def glyph_scatter_affine(feat, scale, shift, g_start, g_x1, g_w):
+    lib = _lib.load()
+    _need_cuda(feat, scale, shift, g_start, g_x1, g_w)
+    B, S, FW, C = feat.shape
+    out = torch.empty_like(feat)
+    _lib.check(lib.mnet_glyph_scatter_affine(_p(feat), _p(scale), _p(shift), _p(out), _dt(feat), B, S, C, FW,
+                                             _p(g_start), _p(g_x1), _p(g_w), _stream()), "mnet_glyph_scatter_affine")
+    return out
+
+
+def layernorm(x, gamma, beta, eps=1e-5):
+    lib = _lib.load()
+    _need_cuda(x, gamma, beta)
+    rows, d = x.shape
+    y = torch.empty_like(x)
+    _lib.check(lib.mnet_layernorm(_p(x), _p(gamma), _p(beta), _p(y), rows, d, eps, _stream()), "mnet_layernorm")
+    return y
+
+
+def token_mix(x, ln_g, ln_b, wgt, bias, eps=1e-5):
+    lib = _lib.load()
+    _need_cuda(x, ln_g, ln_b, wgt, bias)
+    B, T, D = x.shape
+    J = wgt.shape[0]
+    y = torch.empty((B, J, D), dtype=torch.float32, device=x.device)
+    _lib.check(lib.mnet_token_mix(_p(x), _p(ln_g), _p(ln_b), _p(wgt), _p(bias), _p(y), B, T, D, J, eps, _stream()),
+               "mnet_token_mix")
+    return y
+
+
+def attention(qkv, B, N, H, scale):
+    lib = _lib.load()
+    _need_cuda(qkv)
+    out = torch.empty((B * N, H * 64), dtype=torch.float32, device=qkv.device)
+    _lib.check(lib.mnet_attention(_p(qkv), _p(out), B, N, H, scale, _stream()), "mnet_attention")
+    return out
+
+
+def pixelnorm(x):
+    lib = _lib.load()
+    _need_cuda(x)
+    y = torch.empty_like(x)
+    _lib.check(lib.mnet_pixelnorm(_p(x), _p(y), x.shape[0], x.shape[1], _stream()), "mnet_pixelnorm")
+    return y
+
+
+def embed_gather(emb, labels, dtype, num_classes):
+    lib = _lib.load()
+    _need_cuda(emb, labels)
+    N, nc = labels.shape
+    C = emb.shape[1]
+    out = torch.empty((N, 4, 4 * nc, C), dtype=dtype, device=emb.device)
+    _lib.check(lib.mnet_embed_gather(_p(emb), _p(labels), _p(out), _dt(out), N, nc, C, num_classes, _stream()),
+               "mnet_embed_gather")
+    return out
+
+
+def demod(style, wsq_t):
+    lib = _lib.load()
+    _need_cuda(style, wsq_t)
+    N, cin = style.shape
+    cout = wsq_t.shape[1]
+    out = torch.empty((N, cout), dtype=torch.float32, device=style.device)
+    _lib.check(lib.mnet_demod(_p(style), _p(wsq_t), _p(out), N, cin, cout, _stream()), "mnet_demod")
+    return out
+
+
+def argmax_rows(x):
+    lib = _lib.load()
+    _need_cuda(x)
+    rows, d = x.shape
+    idx = torch.empty((rows,), dtype=torch.int64, device=x.device)
+    _lib.check(lib.mnet_argmax_rows(_p(x), _p(idx), rows, d, _stream()), "mnet_argmax_rows")
+    return idx
+
+
+def convert(x, dtype):
+    if x.dtype == dtype:
+        return x
+    lib = _lib.load()
+    _need_cuda(x)
+    y = torch.empty(x.shape, dtype=dtype, device=x.device)
+    _lib.check(lib.mnet_convert(_p(x), _dt(x), _p(y), _dt(y), x.numel(), _stream()), "mnet_convert")
+    return y
+
+
+def fused_bias_act(x, bias, negative_slope=0.2, scale=2 ** 0.5):
+    """basicsr.ops.fused_act.fused_leaky_relu semantics on a contiguous fp32 [N,C,...] tensor."""
+    lib = _lib.load()
+    _need_cuda(x, bias)
+    if x.dtype != torch.float32:
+        raise TypeError("fused_bias_act: fp32 expected")
+    C = x.shape[1]
+    inner = 1
+    for s in x.shape[2:]:
+        inner *= s
+    y = torch.empty_like(x)
+    _lib.check(lib.mnet_fused_bias_act(_p(x), _p(bias), _p(y), x.numel(), C, inner, negative_slope, scale, _stream()),
+               "mnet_fused_bias_act")
+    return y

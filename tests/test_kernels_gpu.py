@@ -1,0 +1,310 @@
+"""-m gpu: every C-ABI kernel against a plain PyTorch fp32 CPU reference of the same op (the op-level
+oracle for floating-point kernels).  Tolerances: fp32 kernels 2e-5 relative to the output scale (summation
+order only); f16 kernels are fed fp16-rounded inputs, the reference is computed in fp32 from the same rounded
+values, so the only differences are accumulation order and the final fp16 rounding (2e-3 relative)."""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda"
+
+
+def _ops():
+    from marconet_amd import ops
+    return ops
+
+
+def _rnd(shape, seed, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return torch.randn(shape, generator=g) * scale
+
+
+def _q(t, dtype):
+    """round through the storage dtype (identity for fp32)"""
+    return t.to(dtype).float()
+
+
+def _nhwc(t, dtype):   # NCHW cpu fp32 -> NHWC device
+    return t.permute(0, 2, 3, 1).contiguous().to(dtype).to(DEV)
+
+
+def _nchw(t):          # NHWC device -> NCHW cpu fp32
+    return t.float().cpu().permute(0, 3, 1, 2).contiguous()
+
+
+def _pack_w(w, dtype):  # OIHW -> [O,KH,KW,I]
+    return w.permute(0, 2, 3, 1).contiguous().to(dtype).to(DEV)
+
+
+def _tol(dtype):
+    return 2e-5 if dtype == torch.float32 else 2.5e-3
+
+
+def _check(name, got, ref, dtype, extra=1.0):
+    scale = max(ref.abs().max().item(), 1e-6)
+    err = (got - ref).abs().max().item()
+    print("%-44s max|d|=%.3e  ref max=%.3e  rel=%.3e" % (name, err, scale, err / scale))
+    assert err <= _tol(dtype) * extra * scale, "%s: err %.3e > tol (scale %.3e)" % (name, err, scale)
+
+
+ACT_REF = {
+    0: lambda v: v,
+    1: F.relu,
+    2: lambda v: F.leaky_relu(v, 0.2),
+    3: lambda v: F.leaky_relu(v, 0.2) * 2 ** 0.5,
+    4: torch.tanh,
+    5: F.gelu,
+    6: torch.sigmoid,
+}
+
+CONV_CASES = [
+    # n, h, w, c0, c1, cout, k, stride, pad
+    (2, 9, 13, 64, 0, 128, 3, (1, 1), 1),
+    (1, 16, 24, 32, 0, 64, 3, (1, 1), 1),
+    (3, 7, 11, 16, 0, 32, 3, (2, 1), 1),
+    (2, 12, 20, 8, 0, 8, 3, (1, 1), 1),
+    (2, 12, 20, 64, 0, 256, 3, (2, 2), 1),
+    (2, 8, 8, 128, 0, 136, 1, (1, 1), 0),
+    (2, 8, 16, 256, 128, 256, 3, (1, 1), 1),
+    (1, 32, 32, 512, 0, 256, 3, (1, 1), 1),
+    (4, 6, 10, 24, 8, 48, 1, (2, 1), 0),
+]
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float16])
+@pytest.mark.parametrize("case", CONV_CASES)
+def test_conv_plain(case, dtype):
+    ops = _ops()
+    n, h, w, c0, c1, cout, k, stride, pad = case
+    x = _q(_rnd((n, c0 + c1, h, w), 1), dtype)
+    wt = _q(_rnd((cout, c0 + c1, k, k), 2, 1.0 / math.sqrt((c0 + c1) * k * k)), dtype)
+    ref = F.conv2d(x, wt, stride=stride, padding=pad)
+    x0 = _nhwc(x[:, :c0], dtype)
+    x1 = _nhwc(x[:, c0:], dtype) if c1 else None
+    y = ops.conv2d(x0, _pack_w(wt, dtype), cout, k, k, stride, (pad, pad), x1=x1)
+    torch.cuda.synchronize()
+    _check("conv %s %s" % (case, dtype), _nchw(y), ref, dtype)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float16])
+@pytest.mark.parametrize("act", [0, 1, 2, 3, 4, 5, 6])
+def test_conv_epilogue(act, dtype):
+    ops = _ops()
+    n, h, w, cin, cout = 3, 10, 14, 32, 72
+    x = _q(_rnd((n, cin, h, w), 3), dtype)
+    wt = _q(_rnd((cout, cin, 3, 3), 4, 1.0 / math.sqrt(cin * 9)), dtype)
+    bias = _rnd((cout,), 5, 0.3)
+    osc = _rnd((n, cout), 6).abs() + 0.5
+    res = _q(_rnd((n, cout, h, w), 7), dtype)
+    ref = F.conv2d(x, wt, padding=1) * osc[:, :, None, None] + bias[None, :, None, None] + res
+    ref = ACT_REF[act](ref)
+    y = ops.conv2d(_nhwc(x, dtype), _pack_w(wt, dtype), cout, 3, 3, (1, 1), (1, 1), out_scale=osc.to(DEV),
+                   bias=bias.to(DEV), residual=_nhwc(res, dtype), act=act)
+    torch.cuda.synchronize()
+    _check("conv epilogue act=%d %s" % (act, dtype), _nchw(y), ref, dtype, extra=2.0)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float16])
+@pytest.mark.parametrize("swish", [False, True])
+def test_conv_prologue_affine_validw(swish, dtype):
+    """GroupNorm-affine + swish prologue and ragged valid width (per-glyph windows, networks.py:425-448)."""
+    ops = _ops()
+    n, h, w, cin, cout = 5, 8, 12, 64, 64
+    x = _q(_rnd((n, cin, h, w), 8), dtype)
+    wt = _q(_rnd((cout, cin, 3, 3), 9, 1.0 / math.sqrt(cin * 9)), dtype)
+    sc = _rnd((n, cin), 10).abs() + 0.5
+    sh = _rnd((n, cin), 11, 0.3)
+    vw = torch.tensor([12, 7, 1, 12, 9], dtype=torch.int32)
+    xin = x * sc[:, :, None, None] + sh[:, :, None, None]
+    if swish:
+        xin = xin * torch.sigmoid(xin)
+    xin = _q(xin, dtype)          # kernel rounds the transformed operand to the storage dtype
+    refs = []
+    for i in range(n):
+        v = int(vw[i])
+        r = torch.zeros(1, cout, h, w)
+        r[..., :v] = F.conv2d(xin[i:i + 1, :, :, :v], wt, padding=1)
+        refs.append(r)
+    ref = torch.cat(refs)
+    y = ops.conv2d(_nhwc(x, dtype), _pack_w(wt, dtype), cout, 3, 3, (1, 1), (1, 1), in_scale=sc.to(DEV),
+                   in_shift=sh.to(DEV), in_swish=swish, valid_w=vw.to(DEV))
+    torch.cuda.synchronize()
+    got = _nchw(y)
+    for i in range(n):
+        got[i, :, :, int(vw[i]):] = 0       # columns beyond valid_w are unspecified
+    _check("conv prologue swish=%s %s" % (swish, dtype), got, ref, dtype, extra=4.0)
+
+
+def test_conv_patch_embed_fp32():
+    """8x8 stride-8 conv over NHWC [B,8,512,512] == Rearrange + Linear(32768,512) (textvit_arch.py:32-35), + pos-emb."""
+    ops = _ops()
+    B = 2
+    feat = _rnd((B, 512, 8, 512), 12)
+    W = _rnd((512, 32768), 13, 1.0 / math.sqrt(32768))
+    b = _rnd((512,), 14, 0.1)
+    pe = _rnd((64, 512), 15)
+    tok = feat.reshape(B, 512, 8, 64, 8).permute(0, 3, 2, 4, 1).reshape(B, 64, 32768)
+    ref = F.linear(tok, W, b) + pe
+    y = ops.conv2d(_nhwc(feat, torch.float32), W.to(DEV), 512, 8, 8, (8, 8), (0, 0), bias=b.to(DEV),
+                   residual=pe.to(DEV).reshape(1, 1, 64, 512), res_mod=64)
+    torch.cuda.synchronize()
+    _check("patch embed", y.cpu().reshape(B, 64, 512), ref, torch.float32, extra=4.0)
+
+
+def test_linear_cls_fp32():
+    ops = _ops()
+    x = _rnd((128, 512), 16)
+    W = _rnd((6736, 512), 17, 1.0 / math.sqrt(512))
+    b = _rnd((6736,), 18, 0.1)
+    ref = F.gelu(F.linear(x, W, b))
+    y = ops.linear(x.to(DEV), W.to(DEV), 6736, bias=b.to(DEV), act=ops.ACT_GELU)
+    torch.cuda.synchronize()
+    _check("linear 512->6736 gelu", y.cpu(), ref, torch.float32)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float16])
+def test_layout_roundtrip(dtype):
+    ops = _ops()
+    x = _rnd((3, 3, 32, 50), 19)
+    y = ops.nchw_to_nhwc(x.to(DEV), dtype, c_ld=8)
+    torch.cuda.synchronize()
+    got = y.float().cpu()
+    assert (got[..., 3:] == 0).all()
+    assert torch.equal(got[..., :3].permute(0, 3, 1, 2), _q(x, dtype))
+    back = ops.nhwc_to_nchw(y, c=3).cpu()
+    assert torch.equal(back, _q(x, dtype))
+    x2 = _rnd((2, 70, 5, 9), 20)
+    y2 = ops.nchw_to_nhwc(x2.to(DEV), dtype)
+    assert torch.equal(ops.nhwc_to_nchw(y2).cpu(), _q(x2, dtype))
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float16])
+def test_upsample2x(dtype):
+    ops = _ops()
+    x = _q(_rnd((2, 16, 5, 7), 21), dtype)
+    ref = F.interpolate(x, scale_factor=2, mode="bilinear", align_corners=False)
+    y = ops.upsample2x(_nhwc(x, dtype))
+    torch.cuda.synchronize()
+    _check("upsample2x %s" % dtype, _nchw(y), ref, dtype)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float16])
+@pytest.mark.parametrize("c", [64, 256, 512])
+def test_groupnorm_affine(c, dtype):
+    ops = _ops()
+    n, h, w = 3, 16, 40
+    x = _q(_rnd((n, c, h, w), 22) * 2 + 0.7, dtype)
+    gamma, beta = 1 + 0.1 * _rnd((c,), 23), 0.1 * _rnd((c,), 24)
+    vw = torch.tensor([40, 17, 3], dtype=torch.int32)
+    sc, sh = ops.groupnorm_affine(_nhwc(x, dtype), gamma.to(DEV), beta.to(DEV), 1e-6, vw.to(DEV))
+    torch.cuda.synchronize()
+    for i in range(n):
+        v = int(vw[i])
+        ref = F.group_norm(x[i:i + 1, :, :, :v], c // 32, gamma, beta, 1e-6)
+        got = x[i:i + 1, :, :, :v] * sc[i].cpu()[None, :, None, None] + sh[i].cpu()[None, :, None, None]
+        _check("groupnorm c=%d img=%d %s" % (c, i, dtype), got, ref, torch.float32, extra=2.0)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float16])
+@pytest.mark.parametrize("S", [32, 64])
+def test_adain_crop_and_scatter(S, dtype):
+    ops = _ops()
+    C, B, FW = 256, 2, S * 16
+    half = S // 2
+    feat = _q(_rnd((B, C, S, FW), 25), dtype)
+    windows = [(0, 0, 21 * S // 32), (0, FW // 2 - half, S), (0, FW // 2 - half + 5, S), (1, FW - 17 * S // 32, 17 * S // 32), (1, 3, S)]
+    G = len(windows)
+    prior = _q(_rnd((G, C, S, S), 26) * 1.5 + 0.2, dtype)
+    g_img = torch.tensor([wd[0] for wd in windows], dtype=torch.int32)
+    g_x1 = torch.tensor([wd[1] for wd in windows], dtype=torch.int32)
+    g_w = torch.tensor([wd[2] for wd in windows], dtype=torch.int32)
+    g_y1 = torch.tensor([half - int(wd[2] / 2) for wd in windows], dtype=torch.int32)
+    out = ops.adain_crop_concat(_nhwc(prior, dtype), _nhwc(feat, dtype), g_img.to(DEV), g_x1.to(DEV), g_y1.to(DEV), g_w.to(DEV))
+    torch.cuda.synchronize()
+    got = _nchw(out)
+
+    def ms(f):
+        v = f.reshape(f.shape[0], f.shape[1], -1)
+        return v.mean(2)[:, :, None, None], (v.var(2) + 1e-5).sqrt()[:, :, None, None]
+
+    for g, (b, x1, gw) in enumerate(windows):
+        y1 = int(g_y1[g])
+        cp, cl = prior[g:g + 1, :, :, y1:y1 + gw], feat[b:b + 1, :, :, x1:x1 + gw]
+        lm, ls = ms(cl)
+        pm, ps = ms(cp)
+        ref = torch.cat(((cp - pm) / ps * ls + lm, cl), dim=1)
+        _check("adain S=%d glyph %d %s" % (S, g, dtype), got[g:g + 1, :, :, :gw], ref, dtype, extra=2.0)
+        assert (got[g, :, :, gw:] == 0).all()
+    # ordered scatter
+    scale = _q(_rnd((G, C, S, S), 27), dtype)
+    shift = _q(_rnd((G, C, S, S), 28), dtype)
+    g_start = torch.tensor([0, 3, 5], dtype=torch.int32)
+    res = torch.zeros_like(feat)
+    for g, (b, x1, gw) in enumerate(windows):
+        res[b, :, :, x1:x1 + gw] = feat[b, :, :, x1:x1 + gw] * scale[g, :, :, :gw] + shift[g, :, :, :gw]
+    ref = feat + res
+    o = ops.glyph_scatter_affine(_nhwc(feat, dtype), _nhwc(scale, dtype), _nhwc(shift, dtype), g_start.to(DEV), g_x1.to(DEV), g_w.to(DEV))
+    torch.cuda.synchronize()
+    _check("glyph scatter S=%d %s" % (S, dtype), _nchw(o), ref, dtype)
+
+
+def test_layernorm_tokenmix_attention():
+    ops = _ops()
+    x = _rnd((130, 512), 29) * 3 + 1
+    g, b = 1 + 0.1 * _rnd((512,), 30), 0.1 * _rnd((512,), 31)
+    y = ops.layernorm(x.to(DEV), g.to(DEV), b.to(DEV))
+    _check("layernorm 512", y.cpu(), F.layer_norm(x, (512,), g, b, 1e-5), torch.float32)
+    x64 = _rnd((70, 64), 32)
+    g64, b64 = 1 + 0.1 * _rnd((64,), 33), 0.1 * _rnd((64,), 34)
+    y = ops.layernorm(x64.to(DEV), g64.to(DEV), b64.to(DEV))
+    _check("layernorm 64", y.cpu(), F.layer_norm(x64, (64,), g64, b64, 1e-5), torch.float32)
+    # token mix: LN over the token axis then Linear(64 -> J)
+    for J in (16, 1):
+        xt = _rnd((3, 64, 512), 35)
+        W, bb = _rnd((J, 64), 36, 0.125), _rnd((J,), 37, 0.1)
+        ref = F.linear(F.layer_norm(xt.permute(0, 2, 1), (64,), g64, b64, 1e-5), W, bb).permute(0, 2, 1)
+        y = ops.token_mix(xt.to(DEV), g64.to(DEV), b64.to(DEV), W.to(DEV), bb.to(DEV))
+        _check("token_mix J=%d" % J, y.cpu(), ref, torch.float32)
+    for N in (64, 16):
+        B, H = 3, 8
+        qkv = _rnd((B, N, 3 * 512), 38)
+        q, k, v = [t.reshape(B, N, H, 64).permute(0, 2, 1, 3) for t in qkv.chunk(3, dim=-1)]
+        att = (torch.matmul(q, k.transpose(-1, -2)) * 0.125).softmax(-1)
+        ref = torch.matmul(att, v).permute(0, 2, 1, 3).reshape(B * N, 512)
+        y = ops.attention(qkv.to(DEV), B, N, H, 0.125)
+        _check("attention N=%d" % N, y.cpu(), ref, torch.float32)
+
+
+def test_gan_small_ops():
+    ops = _ops()
+    x = _rnd((37, 512), 39)
+    y = ops.pixelnorm(x.to(DEV))
+    _check("pixelnorm", y.cpu(), x * torch.rsqrt(torch.mean(x ** 2, dim=1, keepdim=True) + 1e-8), torch.float32)
+    emb = _rnd((100, 512), 40)
+    labels = torch.tensor([[3, 99], [0, 50], [7, 7]], dtype=torch.int64)
+    for dtype in (torch.float32, torch.float16):
+        o = ops.embed_gather(emb.to(DEV), labels.to(DEV), dtype, 100)
+        ref = torch.cat([emb[labels[:, j]][:, :, None, None].expand(3, 512, 4, 4) for j in range(2)], dim=3)
+        assert torch.equal(_nchw(o), _q(ref, dtype))
+    s = _rnd((9, 256), 41) + 1
+    w = _rnd((128, 256, 3, 3), 42)
+    scale = 1 / math.sqrt(256 * 9)
+    wmod = scale * w[None] * s[:, None, :, None, None]
+    ref = torch.rsqrt(wmod.pow(2).sum([2, 3, 4]) + 1e-8)
+    wsq_t = ((scale * w) ** 2).sum([2, 3]).t().contiguous()
+    d = ops.demod(s.to(DEV), wsq_t.to(DEV))
+    _check("demod", d.cpu(), ref, torch.float32, extra=2.0)
+    lg = _rnd((70, 6736), 43)
+    lg[5, 100] = lg[5, 200] = 50.0
+    assert torch.equal(ops.argmax_rows(lg.to(DEV)).cpu(), lg.argmax(-1))
+    xx = _rnd((4, 12, 5, 6), 44)
+    bb = _rnd((12,), 45)
+    y = ops.fused_bias_act(xx.to(DEV), bb.to(DEV))
+    _check("fused_bias_act", y.cpu(), F.leaky_relu(xx + bb.view(1, -1, 1, 1), 0.2) * 2 ** 0.5, torch.float32)
+    h = ops.convert(xx.to(DEV), torch.float16)
+    assert torch.equal(h.cpu(), xx.half())
+    assert torch.equal(ops.convert(h, torch.float32).cpu(), xx.half().float())
