@@ -1,0 +1,446 @@
+"""MI355X-native ``TextContextEncoderV2`` / ``TSPGAN`` / ``TSPSRNet`` — drop-in for the reference's
+models/networks.py: same class names, constructor defaults, parameter/buffer names and shapes
+(``load_state_dict(..., strict=True)`` with the reference checkpoints' key set), same ``forward()`` call forms
+and return shapes (fp32, NCHW, on the input's device).
+
+Internally nothing of the reference's execution survives: activations are NHWC in the compute dtype
+(fp32 "parity" mode or fp16 "throughput" mode, ``set_precision`` / env MARCONET_PRECISION), every conv /
+linear is one launch of the MFMA implicit-GEMM kernel with fused prologue/epilogue, weights are folded and
+repacked once per load, the modulated conv is applied on the activation side, and TSPSRNet's per-glyph Python
+loops become batched kernels over all glyphs of the batch.  The child ``nn.Module``s hold parameters only.
+"""
+import math
+
+import torch
+import torch.nn as nn
+
+from . import ops
+from .glyphs import GlyphTables
+from .packing import (PackCache, default_precision, equal_linear_scale, pack_conv_weight, pack_vec, sn_fold,
+                      torch_dtype)
+from .resnet import resnet45stride as resnet45
+from .textvit_arch import TextViT as TextEncoder
+
+RGB_PAD = 8      # 3-channel tensors are carried with 8 channels (one 16-byte fp16 chunk)
+
+
+class _Precision:
+    def set_precision(self, precision):
+        """'fp32' (parity mode, ≤1e-3 vs the CPU reference) or 'fp16' (throughput mode; fp32 accumulate/statistics)."""
+        if precision not in ("fp32", "fp16"):
+            raise ValueError("precision must be 'fp32' or 'fp16'")
+        self.precision = precision
+        for m in self.children():
+            if hasattr(m, "precision"):
+                m.precision = precision
+        return self
+
+
+# =====================================================================================================
+# 1) TextContextEncoderV2  (models/networks.py:27-45)
+# =====================================================================================================
+class TextContextEncoderV2(nn.Module, _Precision):
+    """LR image → (character logits [B,64,6736], (left,right) locs [B,32], font style w [B,512])."""
+
+    def __init__(self, dim=512, num_classes=6736):
+        super().__init__()
+        self.resnet = resnet45()
+        self.transformer = TextEncoder(num_classes=num_classes, dim=512, max_length=16)
+        self.precision = default_precision()
+        self.resnet.precision = self.precision
+
+    def forward(self, lq):
+        with torch.no_grad():
+            self.resnet.precision = self.precision
+            x = ops.nchw_to_nhwc(lq.contiguous().float(), torch_dtype(self.precision), c_ld=8)
+            feat = self.resnet.forward_nhwc(x)
+            feat = ops.convert(feat, torch.float32)          # the ViT always runs in fp32
+            return self.transformer.forward_nhwc(feat)
+
+
+# =====================================================================================================
+# 2) TSPGAN  (models/networks.py:51-321) — parameter holders
+# =====================================================================================================
+class PixelNorm(nn.Module):
+    pass
+
+
+class EqualLinear(nn.Module):
+    def __init__(self, in_channels, out_channels, bias=True, bias_init_val=0, lr_mul=1, activation=None):
+        super().__init__()
+        self.in_channels, self.out_channels, self.lr_mul, self.activation = in_channels, out_channels, lr_mul, activation
+        self.scale = equal_linear_scale(in_channels, lr_mul)
+        self.weight = nn.Parameter(torch.randn(out_channels, in_channels).div_(lr_mul))
+        if bias:
+            self.bias = nn.Parameter(torch.zeros(out_channels).fill_(bias_init_val))
+        else:
+            self.register_parameter("bias", None)
+
+
+class SelectText(nn.Module):
+    def __init__(self, class_num, channel, size=4):
+        super().__init__()
+        self.size = size
+        self.TextEmbeddings = nn.Parameter(torch.randn(class_num, channel, 1, 1))
+
+
+class ModulatedConv2d(nn.Module):
+    def __init__(self, in_channel, out_channel, kernel_size, style_dim, demodulate=True, upsample=False,
+                 downsample=False, blur_kernel=(1, 3, 3, 1)):
+        super().__init__()
+        self.eps = 1e-8
+        self.kernel_size, self.in_channel, self.out_channel = kernel_size, in_channel, out_channel
+        self.upsample, self.downsample, self.demodulate = upsample, downsample, demodulate
+        self.scale = 1 / math.sqrt(in_channel * kernel_size ** 2)
+        self.padding = kernel_size // 2
+        self.weight = nn.Parameter(torch.randn(1, out_channel, in_channel, kernel_size, kernel_size))
+        self.modulation = EqualLinear(style_dim, in_channel, bias=True, bias_init_val=1, lr_mul=1, activation=None)
+
+
+class FusedLeakyReLU(nn.Module):
+    """parameter holder of basicsr's FusedLeakyReLU (bias [C]); the math is the conv epilogue ACT_LRELU_SQRT2."""
+
+    def __init__(self, channel, negative_slope=0.2, scale=2 ** 0.5):
+        super().__init__()
+        self.bias = nn.Parameter(torch.zeros(channel))
+        self.negative_slope, self.scale = negative_slope, scale
+
+
+class StyledConv(nn.Module):
+    def __init__(self, in_channel, out_channel, kernel_size, style_dim, upsample=False, blur_kernel=(1, 3, 3, 1),
+                 demodulate=True):
+        super().__init__()
+        self.conv = ModulatedConv2d(in_channel, out_channel, kernel_size, style_dim, upsample=upsample,
+                                    blur_kernel=blur_kernel, demodulate=demodulate)
+        self.bias = nn.Parameter(torch.zeros(1, out_channel, 1, 1))
+        self.activate = FusedLeakyReLU(out_channel)
+
+
+class ToRGB(nn.Module):
+    def __init__(self, in_channel, style_dim, upsample=True, blur_kernel=(1, 3, 3, 1)):
+        super().__init__()
+        self.upsample = upsample
+        self.conv = ModulatedConv2d(in_channel, 3, 1, style_dim, demodulate=False)
+        self.bias = nn.Parameter(torch.zeros(1, 3, 1, 1))
+
+
+class TextGenerator(nn.Module):
+    """font style w + character labels → (structure image, prior64, prior32)   (models/networks.py:64-164)."""
+
+    def __init__(self, size, style_dim, n_mlp, class_num, channel_multiplier=1, blur_kernel=(1, 3, 3, 1), lr_mlp=0.01):
+        super().__init__()
+        self.size, self.n_mlp, self.style_dim, self.class_num = size, n_mlp, style_dim, class_num
+        self.style_mlp = nn.Sequential(PixelNorm(), *[
+            EqualLinear(style_dim, style_dim, bias=True, bias_init_val=0, lr_mul=lr_mlp, activation="fused_lrelu")
+            for _ in range(n_mlp)])
+        cm = channel_multiplier
+        self.channels = {4: 512, 8: 512, 16: 512, 32: 512, 64: 256 * cm, 128: 128 * cm, 256: 64 * cm, 512: 32 * cm,
+                         1024: 16 * cm}
+        self.input_text = SelectText(class_num, self.channels[4])
+        self.conv1 = StyledConv(self.channels[4], self.channels[4], 3, style_dim, blur_kernel=blur_kernel)
+        self.to_rgb1 = ToRGB(self.channels[4], style_dim, upsample=False)
+        self.log_size = int(math.log(size, 2))
+        self.convs, self.upsamples, self.to_rgbs = nn.ModuleList(), nn.ModuleList(), nn.ModuleList()
+        cin = self.channels[4]
+        for i in range(3, self.log_size + 1):
+            cout = self.channels[2 ** i]
+            self.convs.append(StyledConv(cin, cout, 3, style_dim, upsample=True, blur_kernel=blur_kernel))
+            self.convs.append(StyledConv(cout, cout, 3, style_dim, blur_kernel=blur_kernel))
+            self.to_rgbs.append(ToRGB(cout, style_dim))
+            cin = cout
+        self.n_latent = self.log_size * 2 - 2
+        self.precision = default_precision()
+        self._cache = PackCache()
+
+    # ------------------------------------------------------------------ packing
+    def _build(self, dtype):
+        pk = {}
+        f = lambda t: t.detach().float().contiguous()
+        pk["mlp"] = []
+        for i in range(1, self.n_mlp + 1):
+            el = self.style_mlp[i]
+            pk["mlp"].append((f(el.weight.detach() * el.scale), f(el.bias.detach() * el.lr_mul)))   # networks.py:192-195
+        pk["emb"] = f(self.input_text.TextEmbeddings.detach().reshape(self.class_num, -1))
+
+        def styled(sc):
+            mc = sc.conv
+            w = mc.scale * mc.weight.detach()[0]                                   # [Cout,Cin,3,3], networks.py:284
+            return dict(cin=mc.in_channel, cout=mc.out_channel, up=mc.upsample,
+                        w=pack_conv_weight(w, dtype),
+                        wsq_t=f((w * w).sum(dim=(2, 3)).t()),                      # [Cin,Cout] for the demod table
+                        mod_w=f(mc.modulation.weight.detach() * mc.modulation.scale), mod_b=f(mc.modulation.bias),
+                        bias=f(sc.bias.detach().reshape(-1) + sc.activate.bias.detach()))   # :244 then :245
+
+        def torgb(tr):
+            mc = tr.conv
+            w = mc.scale * mc.weight.detach()[0]                                   # [3,Cin,1,1]
+            return dict(cin=mc.in_channel, w=pack_conv_weight(w, dtype, cout_mult=RGB_PAD),
+                        mod_w=f(mc.modulation.weight.detach() * mc.modulation.scale), mod_b=f(mc.modulation.bias),
+                        bias=pack_vec(tr.bias, RGB_PAD))
+
+        pk["conv1"] = styled(self.conv1)
+        pk["rgb1"] = torgb(self.to_rgb1)
+        pk["convs"] = [styled(c) for c in self.convs]
+        pk["rgbs"] = [torgb(t) for t in self.to_rgbs]
+        return pk
+
+    # ------------------------------------------------------------------ forward pieces
+    @staticmethod
+    def _styled(L, x, latent):
+        s = ops.linear(latent, L["mod_w"], L["cin"], bias=L["mod_b"])          # modulation EqualLinear (:283)
+        d = ops.demod(s, L["wsq_t"])                                           # rsqrt(Σ (scale·W·s)² + 1e-8) (:286)
+        if L["up"]:
+            x = ops.upsample2x(x)                                              # bilinear ×2 before the conv (:293)
+        return ops.conv2d(x, L["w"], L["cout"], 3, 3, (1, 1), (1, 1), in_scale=s, out_scale=d, bias=L["bias"],
+                          act=ops.ACT_LRELU_SQRT2)
+
+    @staticmethod
+    def _to_rgb(L, x, latent, skip):
+        s = ops.linear(latent, L["mod_w"], L["cin"], bias=L["mod_b"])
+        if skip is not None:
+            skip = ops.upsample2x(skip)                                        # :318-319
+        return ops.conv2d(x, L["w"], RGB_PAD, in_scale=s, bias=L["bias"], residual=skip, act=ops.ACT_TANH)
+
+    def forward_nhwc(self, styles, labels):
+        """→ (image NHWC [N,128,128c,8], prior64 NHWC [N,64,64c,256], prior32 NHWC [N,32,32c,512])."""
+        pk = self._cache.get(self, self.precision, self._build)
+        dtype = torch_dtype(self.precision)
+        lat = ops.pixelnorm(styles)                                            # :170-171
+        for w, b in pk["mlp"]:
+            lat = ops.linear(lat, w, self.style_dim, bias=b, act=ops.ACT_LRELU_SQRT2)
+        x = ops.embed_gather(pk["emb"], labels, dtype, self.class_num)         # SelectText (:205-215)
+        x = self._styled(pk["conv1"], x, lat)
+        skip = self._to_rgb(pk["rgb1"], x, lat, None)
+        p64 = p32 = None
+        nc = labels.shape[1]
+        for lvl in range(len(pk["rgbs"])):
+            x = self._styled(pk["convs"][2 * lvl], x, lat)
+            x = self._styled(pk["convs"][2 * lvl + 1], x, lat)
+            skip = self._to_rgb(pk["rgbs"][lvl], x, lat, skip)
+            if x.shape[2] == 64 * nc:
+                p64 = x
+            if x.shape[2] == 32 * nc:
+                p32 = x
+        return skip, p64, p32
+
+    def forward(self, styles, labels, noise=None):
+        with torch.no_grad():
+            styles = styles.contiguous().float()
+            labels = labels.to(styles.device).contiguous().long()
+            if labels.dim() != 2 or labels.shape[0] != styles.shape[0]:
+                raise ValueError("labels must be [N,c] with N == styles.size(0)")
+            if labels.numel() and (int(labels.min()) < 0 or int(labels.max()) >= self.class_num):
+                # the reference fails on label -1 (empty slice → torch.cat error, caught by test_sr.py:181-190)
+                raise RuntimeError("label index out of range [0,%d)" % self.class_num)
+            img, p64, p32 = self.forward_nhwc(styles, labels)
+            out = ops.nhwc_to_nchw(img, c=3), ops.nhwc_to_nchw(p64), ops.nhwc_to_nchw(p32)
+            # keep the NHWC originals reachable so TSPSRNet can skip the NCHW→NHWC round trip
+            out[1]._mnet_nhwc, out[2]._mnet_nhwc = p64, p32
+            return out
+
+
+class TSPGAN(nn.Module, _Precision):
+    def __init__(self, out_size=128, num_style_feat=512, class_num=6736, num_mlp=8):
+        super().__init__()
+        self.TextGenerator = TextGenerator(size=out_size, style_dim=num_style_feat, n_mlp=num_mlp, class_num=class_num)
+        self.precision = default_precision()
+
+    def forward(self, styles, labels, noise):
+        self.TextGenerator.precision = self.precision
+        return self.TextGenerator(styles, labels, noise)
+
+
+# =====================================================================================================
+# 3) TSPSRNet  (models/networks.py:328-533)
+# =====================================================================================================
+class _SNConv(nn.Module):
+    """Holder with the old-style ``torch.nn.utils.spectral_norm`` parametrisation of an nn.Conv2d
+    (networks.py:14): Parameters ``bias``, ``weight_orig``; buffers ``weight_u``, ``weight_v``."""
+
+    def __init__(self, cin, cout, k=3, stride=1):
+        super().__init__()
+        self.in_channels, self.out_channels, self.kernel_size, self.stride = cin, cout, k, stride
+        conv = nn.Conv2d(cin, cout, k, stride, k // 2)
+        self.bias = nn.Parameter(conv.bias.detach().clone())
+        self.weight_orig = nn.Parameter(conv.weight.detach().clone())
+        nrm = lambda t: t / (t.norm() + 1e-12)
+        self.register_buffer("weight_u", nrm(torch.randn(cout)))
+        self.register_buffer("weight_v", nrm(torch.randn(cin * k * k)))
+
+
+def GroupNorm(in_channels):
+    assert in_channels % 32 == 0
+    return nn.GroupNorm(num_groups=in_channels // 32, num_channels=in_channels, eps=1e-6, affine=True)
+
+
+class ResTextBlockV2(nn.Module):
+    def __init__(self, in_channels, out_channels=None):
+        super().__init__()
+        self.in_channels = in_channels
+        self.out_channels = in_channels if out_channels is None else out_channels
+        self.norm1 = GroupNorm(in_channels)
+        self.conv1 = _SNConv(in_channels, self.out_channels)
+        self.norm2 = GroupNorm(self.out_channels)
+        self.conv2 = _SNConv(self.out_channels, self.out_channels)
+        if self.in_channels != self.out_channels:
+            self.conv_out = nn.Conv2d(in_channels, self.out_channels, kernel_size=1, stride=1, padding=0)
+
+
+def _seq(*mods):
+    return nn.Sequential(*mods)
+
+
+class TSPSRNet(nn.Module, _Precision):
+    """LR image + per-image structure priors (64², 32²) + glyph locations → SR image [B,3,128,2048]."""
+
+    def __init__(self, in_channel=3, dim_channel=256):
+        super().__init__()
+        D = dim_channel
+        I = nn.Identity            # index placeholders for the reference's parameter-free layers
+        self.conv_first_32 = _seq(_SNConv(in_channel, D // 4), I())
+        self.conv_first_16 = _seq(_SNConv(D // 4, D // 2, 3, 2), I())
+        self.conv_first_8 = _seq(_SNConv(D // 2, D, 3, 2), I(), _SNConv(D, D))
+        self.conv_body_16 = _seq(_SNConv(D + D // 2, D), I(), _SNConv(D, D))
+        self.conv_body_32 = _seq(_SNConv(D + D // 4, D), I(), _SNConv(D, D))
+        self.conv_up = _seq(I(), _SNConv(D, D), I(), ResTextBlockV2(D, D), _SNConv(D, D))
+        self.conv_final = _seq(_SNConv(D, D // 2), I(), I(), _SNConv(D // 2, D // 4), I(),
+                               ResTextBlockV2(D // 4, D // 4), _SNConv(D // 4, 3), I())
+        self.conv_32_scale = _seq(_SNConv(D, D), I(), _SNConv(D, D))
+        self.conv_32_shift = _seq(_SNConv(D, D), I(), _SNConv(D, D))
+        self.conv_32_fuse = _seq(ResTextBlockV2(2 * D, D))
+        self.conv_32_to256 = _seq(_SNConv(512, D), I(), _SNConv(D, D))
+        self.conv_64_scale = _seq(_SNConv(D, D), I(), _SNConv(D, D))
+        self.conv_64_shift = _seq(_SNConv(D, D), I(), _SNConv(D, D))
+        self.conv_64_fuse = _seq(ResTextBlockV2(2 * D, D))
+        self.dim = D
+        self.precision = default_precision()
+        self._cache = PackCache()
+
+    # ------------------------------------------------------------------ packing (SN fold, K18)
+    def _build(self, dtype):
+        pk = {}
+
+        def sn(name, m, cout_mult=4):
+            w = sn_fold(m.weight_orig, m.weight_u, m.weight_v)
+            cp = (m.out_channels + cout_mult - 1) // cout_mult * cout_mult
+            pk[name] = dict(w=pack_conv_weight(w, dtype, cout_mult=cout_mult), b=pack_vec(m.bias, cp), cout=cp,
+                            stride=(m.stride, m.stride))
+
+        def res(name, m):
+            sn(name + ".conv1", m.conv1)
+            sn(name + ".conv2", m.conv2)
+            f = lambda t: t.detach().float().contiguous()
+            pk[name + ".norm1"] = (f(m.norm1.weight), f(m.norm1.bias))
+            pk[name + ".norm2"] = (f(m.norm2.weight), f(m.norm2.bias))
+            if hasattr(m, "conv_out"):
+                pk[name + ".conv_out"] = dict(w=pack_conv_weight(m.conv_out.weight.detach(), dtype), b=f(m.conv_out.bias))
+
+        for name in ("conv_first_32", "conv_first_16"):
+            sn(name + ".0", getattr(self, name)[0])
+        for name in ("conv_first_8", "conv_body_16", "conv_body_32", "conv_32_scale", "conv_32_shift", "conv_32_to256",
+                     "conv_64_scale", "conv_64_shift"):
+            sn(name + ".0", getattr(self, name)[0])
+            sn(name + ".2", getattr(self, name)[2])
+        sn("conv_up.1", self.conv_up[1]); res("conv_up.3", self.conv_up[3]); sn("conv_up.4", self.conv_up[4])
+        sn("conv_final.0", self.conv_final[0]); sn("conv_final.3", self.conv_final[3])
+        res("conv_final.5", self.conv_final[5]); sn("conv_final.6", self.conv_final[6], cout_mult=RGB_PAD)
+        res("conv_32_fuse.0", self.conv_32_fuse[0]); res("conv_64_fuse.0", self.conv_64_fuse[0])
+        return pk
+
+    # ------------------------------------------------------------------ building blocks
+    @staticmethod
+    def _c(pk, name, x, act=ops.ACT_NONE, x1=None, valid_w=None, in_scale=None, in_shift=None, residual=None):
+        L = pk[name]
+        return ops.conv2d(x, L["w"], L["cout"], 3, 3, L["stride"], (1, 1), x1=x1, bias=L["b"], act=act, valid_w=valid_w,
+                          in_scale=in_scale, in_shift=in_shift, in_swish=in_scale is not None, residual=residual)
+
+    def _two(self, pk, name, x, x1=None, valid_w=None):
+        """Sequential(SNconv, LeakyReLU(0.2), SNconv)."""
+        h = self._c(pk, name + ".0", x, ops.ACT_LRELU, x1=x1, valid_w=valid_w)
+        return self._c(pk, name + ".2", h, valid_w=valid_w)
+
+    def _res_block(self, pk, name, x, valid_w=None):
+        """ResTextBlockV2 (networks.py:506-516): GN+swish ride in the conv prologue; skip (+1x1 conv_out) in the epilogue."""
+        s1, h1 = ops.groupnorm_affine(x, *pk[name + ".norm1"], 1e-6, valid_w)
+        h = self._c(pk, name + ".conv1", x, valid_w=valid_w, in_scale=s1, in_shift=h1)
+        s2, h2 = ops.groupnorm_affine(h, *pk[name + ".norm2"], 1e-6, valid_w)
+        skip = x
+        if (name + ".conv_out") in pk:
+            co = pk[name + ".conv_out"]
+            skip = ops.conv2d(x, co["w"], co["b"].numel(), bias=co["b"])
+        return self._c(pk, name + ".conv2", h, valid_w=valid_w, in_scale=s2, in_shift=h2, residual=skip)
+
+    def _prior_transform(self, pk, tag, feat, prior, tab):
+        """All glyphs of the batch at one scale (networks.py:421-449 / :455-482)."""
+        if tab.G == 0:
+            return feat
+        cat = ops.adain_crop_concat(prior, feat, tab.g_img, tab.g_x1, tab.g_y1, tab.g_w)       # AdaIN + crop + cat
+        fused = self._res_block(pk, "conv_%s_fuse.0" % tag, cat, valid_w=tab.g_w)
+        del cat
+        sc = self._two(pk, "conv_%s_scale" % tag, fused, valid_w=tab.g_w)
+        sh = self._two(pk, "conv_%s_shift" % tag, fused, valid_w=tab.g_w)
+        return ops.glyph_scatter_affine(feat, sc, sh, tab.g_start, tab.g_x1, tab.g_w)        # ori + (f*scale+shift)
+
+    @staticmethod
+    def _gather_priors(priors, dtype, channels, size):
+        """list of NCHW fp32 [n_b,C,S,S] (or tensors produced by our TSPGAN, which carry their NHWC original)."""
+        parts = []
+        for p in priors:
+            if p.shape[0] == 0:
+                continue
+            if p.dim() != 4 or p.shape[1] != channels or p.shape[2] != size or p.shape[3] != size:
+                raise ValueError("prior of shape %s, expected [n,%d,%d,%d]" % (tuple(p.shape), channels, size, size))
+            nh = getattr(p, "_mnet_nhwc", None)
+            if nh is not None and nh.dtype == dtype and nh.shape[0] == p.shape[0]:
+                parts.append(nh)
+            else:
+                parts.append(ops.nchw_to_nhwc(p.contiguous().float(), dtype))
+        if not parts:
+            return None
+        return parts[0] if len(parts) == 1 else torch.cat(parts, dim=0)
+
+    # ------------------------------------------------------------------ forward
+    def forward(self, lq, priors64, priors32, locs):
+        with torch.no_grad():
+            pk = self._cache.get(self, self.precision, self._build)
+            dtype = torch_dtype(self.precision)
+            B = lq.shape[0]
+            if len(priors32) > B or len(priors64) > B:
+                raise IndexError("more prior lists (%d / %d) than images (%d)" % (len(priors64), len(priors32), B))
+            x = ops.nchw_to_nhwc(lq.contiguous().float(), dtype, c_ld=8)
+            f32 = self._c(pk, "conv_first_32.0", x, ops.ACT_LRELU)                               # :412
+            f16 = self._c(pk, "conv_first_16.0", f32, ops.ACT_LRELU)                             # :413
+            f8 = self._c(pk, "conv_first_8.2", self._c(pk, "conv_first_8.0", f16, ops.ACT_LRELU))  # :414
+            s16 = self._two(pk, "conv_body_16", ops.upsample2x(f8), x1=f16)                      # :415 (cat-free)
+            s32 = self._two(pk, "conv_body_32", ops.upsample2x(s16), x1=f32)                     # :416
+            del f8, f16, s16, f32, x
+
+            # glyph windows: ONE device→host copy of locs, integer tables back
+            counts32 = [int(p.shape[0]) for p in priors32] + [0] * (B - len(priors32))
+            counts64 = [int(p.shape[0]) for p in priors64] + [0] * (B - len(priors64))
+            locs_host = locs.detach().float().cpu().numpy() if (sum(counts32) + sum(counts64)) else None
+            W32 = s32.shape[2]
+            tab32 = GlyphTables(locs_host, counts32[:B], W32, 16, lq.device) if sum(counts32) else None
+            if tab32 is not None:
+                p32 = self._gather_priors(priors32, dtype, 512, 32)
+                p32 = self._two(pk, "conv_32_to256", p32)                                        # :424
+                s32 = self._prior_transform(pk, "32", s32, p32, tab32)                           # :425-449
+                del p32
+
+            h = self._c(pk, "conv_up.1", ops.upsample2x(s32), ops.ACT_LRELU)                     # conv_up :359-365
+            del s32
+            h = self._res_block(pk, "conv_up.3", h)
+            s64 = self._c(pk, "conv_up.4", h)
+            del h
+            tab64 = GlyphTables(locs_host, counts64[:B], s64.shape[2], 32, lq.device) if sum(counts64) else None
+            if tab64 is not None:
+                p64 = self._gather_priors(priors64, dtype, 256, 64)
+                s64 = self._prior_transform(pk, "64", s64, p64, tab64)                           # :455-482
+                del p64
+
+            h = self._c(pk, "conv_final.0", s64, ops.ACT_LRELU)                                  # conv_final :367-376
+            del s64
+            h = self._c(pk, "conv_final.3", ops.upsample2x(h), ops.ACT_LRELU)
+            h = self._res_block(pk, "conv_final.5", h)
+            out = self._c(pk, "conv_final.6", h, ops.ACT_TANH)
+            return ops.nhwc_to_nchw(out, c=3)

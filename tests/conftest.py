@@ -27,3 +27,16 @@ def report_dir():
     d = os.path.join(ROOT, "gpurun_out")
     os.makedirs(d, exist_ok=True)
     return d
+
+
+@pytest.fixture(scope="session")
+def ckpts():
+    """seeded synthetic state_dicts (encoder, gan, sr) — oracle/synth.py, ~7 s once per session"""
+    from oracle import synth
+    return synth.make_encoder_state_dict(), synth.make_gan_state_dict(), synth.make_sr_state_dict()
+
+
+@pytest.fixture(scope="session")
+def golden():
+    import numpy as np
+    return dict(np.load(os.path.join(ROOT, "tests", "golden", "golden_v1.npz")))

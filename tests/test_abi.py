@@ -1,0 +1,126 @@
+"""not-gpu: the C-ABI library loads, exports every symbol include/marconet_hip.h declares, the ctypes mirror
+of mnet_conv_desc has the C layout, argument validation works without a device, the host-side module tree has
+the reference's state_dict schema, and the product package never imports the oracle."""
+import ctypes
+import json
+import os
+import re
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _header_functions():
+    src = open(os.path.join(ROOT, "include", "marconet_hip.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(mnet_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_library_exports_every_declared_symbol():
+    from marconet_amd import _lib
+    lib = _lib.load()
+    names = _header_functions()
+    assert len(names) >= 19
+    for n in names:
+        assert n in _lib.SYMBOLS, "header symbol %s has no ctypes binding" % n
+        assert getattr(lib, n) is not None
+    assert set(_lib.SYMBOLS) == set(names)
+    assert lib.mnet_abi_version() == 1
+
+
+def test_conv_desc_layout_matches_c():
+    """compile a tiny C program against the header and compare sizeof/offsetof with the ctypes mirror"""
+    from marconet_amd._lib import ConvDesc
+    code = r'''
+#include <stdio.h>
+#include <stddef.h>
+#include "marconet_hip.h"
+int main(void){ printf("%zu %zu %zu %zu %zu %zu\n", sizeof(mnet_conv_desc), offsetof(mnet_conv_desc, x1),
+  offsetof(mnet_conv_desc, wgt), offsetof(mnet_conv_desc, in_scale), offsetof(mnet_conv_desc, residual), offsetof(mnet_conv_desc, y)); return 0; }
+'''
+    d = os.path.join(ROOT, "oracle", "_ref")
+    os.makedirs(d, exist_ok=True)
+    cpath, exe = os.path.join(d, "abi_probe.c"), os.path.join(d, "abi_probe")
+    open(cpath, "w").write(code)
+    subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), cpath, "-o", exe])
+    got = [int(v) for v in subprocess.check_output([exe]).split()]
+    exp = [ctypes.sizeof(ConvDesc), ConvDesc.x1.offset, ConvDesc.wgt.offset, ConvDesc.in_scale.offset,
+           ConvDesc.residual.offset, ConvDesc.y.offset]
+    assert got == exp
+
+
+def test_argument_validation_without_device():
+    from marconet_amd import _lib
+    lib = _lib.load()
+    d = _lib.ConvDesc()
+    assert lib.mnet_conv2d_nhwc(None, None) == -1
+    assert lib.mnet_conv2d_nhwc(ctypes.byref(d), None) == -1 and b"null" in lib.mnet_last_error()
+    d.dtype = 1; d.x0 = 16; d.wgt = 16; d.y = 16; d.n = d.h = d.w = d.ho = d.wo = 4
+    d.c0 = 12; d.cout = 8; d.kh = d.kw = 3; d.stride_h = d.stride_w = 1; d.pad_h = d.pad_w = 1
+    assert lib.mnet_conv2d_nhwc(ctypes.byref(d), None) == -2          # c0 % 8 != 0 → MNET_E_ALIGN
+    d.c0 = 16; d.ho = 5
+    assert lib.mnet_conv2d_nhwc(ctypes.byref(d), None) == -1          # inconsistent output size
+    d.ho = 4
+    assert lib.mnet_conv2d_flops(ctypes.byref(d)) == 2.0 * 4 * 4 * 4 * 8 * 9 * 16
+    assert lib.mnet_layernorm(None, None, None, None, 1, 1, 1e-5, None) == -1
+
+
+def test_ops_refuse_cpu_tensors():
+    from marconet_amd import ops
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        ops.upsample2x(torch.zeros(1, 2, 2, 8))
+
+
+def test_state_dict_schema_matches_reference():
+    from marconet_amd import networks
+    schema = json.load(open(os.path.join(ROOT, "tests", "golden", "state_dict_schema.json")))
+    for name, ref in schema.items():
+        m = getattr(networks, name)()
+        got = {k: list(v.shape) for k, v in m.state_dict().items()}
+        assert list(got) == list(ref["state_dict"]) and got == ref["state_dict"], name
+        assert [n for n, _ in m.named_parameters()] == ref["parameters"]
+        assert [n for n, _ in m.named_buffers()] == ref["buffers"]
+        assert sum(p.numel() for p in m.parameters()) == ref["num_parameters"]      # printed by test_sr.py:59-61
+
+
+def test_synthetic_checkpoints_load_strict(ckpts):
+    from marconet_amd import networks
+    for cls, sd in zip((networks.TextContextEncoderV2, networks.TSPGAN, networks.TSPSRNet), ckpts):
+        m = cls()
+        m.load_state_dict(sd, strict=True)
+        m.eval()
+
+
+def test_glyph_tables_match_oracle_windows():
+    from marconet_amd.glyphs import window
+    from oracle.marconet_oracle import glyph_window
+    rng = np.random.default_rng(0)
+    for feat_w, half in ((512, 16), (1024, 32)):
+        for loc in np.concatenate([rng.random(500).astype(np.float32), np.float32([0, 1e-4, 0.03, 0.97, 0.9999, 1.0])]):
+            x1, x2, y1, y2 = glyph_window(loc, feat_w, half)
+            assert window(loc, feat_w, half) == (x1, x2 - x1, y1)
+
+
+def test_product_never_imports_oracle():
+    """the oracle is test infrastructure: nothing under marconet_amd/ may import or reference it"""
+    for dp, _, files in os.walk(os.path.join(ROOT, "marconet_amd")):
+        for f in files:
+            if f.endswith(".py"):
+                src = open(os.path.join(dp, f)).read()
+                assert not re.search(r"^\s*(from|import)\s+oracle", src, flags=re.M), f
+                assert "F.conv2d" not in src and "torch.nn.functional" not in src, f
+    code = "import sys; import marconet_amd.networks, marconet_amd.ops; assert not any(m == 'oracle' or m.startswith('oracle.') for m in sys.modules)"
+    subprocess.check_call([sys.executable, "-c", code], cwd=ROOT)
+
+
+def test_missing_library_fails_loudly():
+    code = ("import os; os.environ['MARCONET_HIP_LIB']='/nonexistent/lib.so';"
+            "from marconet_amd import _lib\n"
+            "try:\n    _lib.load()\nexcept ImportError as e:\n    print('LOUD', e)\n")
+    out = subprocess.check_output([sys.executable, "-c", code], cwd=ROOT).decode()
+    assert "LOUD" in out and "no CPU/eager fallback" in out
