@@ -63,8 +63,8 @@ int mnet_abi_version(void);
  *   K17 channel concat without materialising it (two sources)   networks.py:415-416
  *   K11 GroupNorm+swish as an input-side affine (scale/shift per (n,c)) + swish   networks.py:508-513
  *
- * y[n,oh,ow,o] = act( out_scale[n,o] * sum_{r,s,i} W[o,r,s,i] * X'[n, oh*sh-ph+r, ow*sw-pw+s, i]
- *                     + bias[o] + residual[n,oh,ow,o] )
+ * y[n,oh,ow,o] = post_scale[n,o] * act( out_scale[n,o] * sum_{r,s,i} W[o,r,s,i] * X'[n, oh*sh-ph+r, ow*sw-pw+s, i]
+ *                                       + bias[o] + residual[n,oh,ow,o] )
  *   X' = X                                   if in_scale == NULL
  *   X' = f(X * in_scale[n,i] + in_shift[n,i]),  f = swish if in_swish else identity
  *   X  = channel-concat(x0[..c0], x1[..c1]);  out-of-image taps (and columns >= valid_w[n]) are zero
@@ -88,6 +88,8 @@ typedef struct {
     const void* residual;       /* NHWC like y, or NULL                                           */
     int32_t res_mod;            /* 0, or residual pixel index = pixel % res_mod (pos-emb add)     */
     int32_t act;                /* mnet_act, applied after bias+residual                          */
+    const float* post_scale;    /* [n][cout] or NULL: multiplied AFTER act — lets a StyledConv emit its
+                                 * output already modulated by the NEXT layer's style (networks.py:283-284) */
     void* y;                    /* NHWC [n,ho,wo,cout]                                            */
 } mnet_conv_desc;
 
@@ -110,6 +112,16 @@ int mnet_nhwc_to_nchw(const void* src, int32_t src_dtype, float* dst, int32_t n,
  * / c % 8 == 0 (f16).  nn.Upsample / F.interpolate at networks.py:268,318,360,370,415,416 */
 int mnet_upsample2x_nhwc(const void* src, void* dst, int32_t dtype, int32_t n, int32_t h, int32_t w,
                          int32_t c, void* stream);
+/* same, output multiplied by scale[n][c] (fp32, may be NULL): the style modulation of an up-sampling StyledConv
+ * applied once per element here instead of once per filter tap inside the conv (networks.py:283-296) */
+int mnet_upsample2x_scale_nhwc(const void* src, void* dst, int32_t dtype, int32_t n, int32_t h, int32_t w,
+                               int32_t c, const float* scale, void* stream);
+
+/* K11 apply: y = f(x * scale[n,c] + shift[n,c]), f = swish if swish else identity (shift may be NULL).
+ * GroupNorm-normalise + swish once per element (networks.py:508-509,511-512) — the conv prologue form of the same
+ * math costs 9 taps x Cout/128 tiles of redundant expf.  x, y NHWC [n, hw, c]; in-place (y == x) allowed. */
+int mnet_affine_act_nhwc(const void* x, void* y, int32_t dtype, int32_t n, int32_t hw, int32_t c,
+                         const float* scale, const float* shift, int32_t swish, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * K11 GroupNorm statistics (groups of 32 channels, eps, affine), networks.py:487-490 — produces the

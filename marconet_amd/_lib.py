@@ -31,6 +31,7 @@ class ConvDesc(ctypes.Structure):
         ("out_scale", c_void_p), ("bias", c_void_p),
         ("residual", c_void_p), ("res_mod", c_int),
         ("act", c_int),
+        ("post_scale", c_void_p),
         ("y", c_void_p),
     ]
 
@@ -44,6 +45,8 @@ SYMBOLS = {
     "mnet_nchw_to_nhwc": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "mnet_nhwc_to_nchw": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "mnet_upsample2x_nhwc": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    "mnet_upsample2x_scale_nhwc": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
+    "mnet_affine_act_nhwc": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_void_p]),
     "mnet_groupnorm_affine": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p,
                                       c_float, c_void_p, c_int, c_void_p, c_void_p, c_void_p]),
     "mnet_adain_crop_concat": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int,

@@ -78,7 +78,8 @@ extern "C" int mnet_nhwc_to_nchw(const void* src, int32_t src_dtype, float* dst,
 // out row 2j+1 = 3/4 * in[j]   + 1/4 * in[j+1]   (j+1 clamped to H-1)        same along W
 template <typename T>
 __global__ void __launch_bounds__(256) upsample2x_kernel(const T* __restrict__ src, T* __restrict__ dst,
-                                                         int H, int W, int C, long long total_chunks) {
+                                                         int H, int W, int C, const float* __restrict__ scale,
+                                                         long long total_chunks) {
     constexpr int N = Vec<T>::N;
     const int cpp = C / N;     // chunks per pixel
     for (long long id = (long long)blockIdx.x * blockDim.x + threadIdx.x; id < total_chunks;
@@ -102,12 +103,17 @@ __global__ void __launch_bounds__(256) upsample2x_kernel(const T* __restrict__ s
         Vec<T>::unpack(ldg16(base + ((size_t)y1 * W + x1) * C), d);
 #pragma unroll
         for (int j = 0; j < N; ++j) o[j] = wy0 * (wx0 * a[j] + wx1 * b[j]) + wy1 * (wx0 * c[j] + wx1 * d[j]);
+        if (scale) {
+            const float* sp = scale + (size_t)n * C + (size_t)ch * N;
+#pragma unroll
+            for (int j = 0; j < N; ++j) o[j] *= sp[j];
+        }
         stg16(dst + (size_t)id * N, Vec<T>::pack(o));
     }
 }
 
-extern "C" int mnet_upsample2x_nhwc(const void* src, void* dst, int32_t dtype, int32_t n, int32_t h, int32_t w,
-                                    int32_t c, void* stream) {
+extern "C" int mnet_upsample2x_scale_nhwc(const void* src, void* dst, int32_t dtype, int32_t n, int32_t h, int32_t w,
+                                          int32_t c, const float* scale, void* stream) {
     MNET_CHECK_ARG(src && dst && n > 0 && h > 0 && w > 0 && c > 0, "upsample2x: bad args");
     MNET_CHECK_ARG(dtype == MNET_F32 || dtype == MNET_F16, "upsample2x: bad dtype");
     const int N = dtype == MNET_F16 ? 8 : 4;
@@ -115,10 +121,15 @@ extern "C" int mnet_upsample2x_nhwc(const void* src, void* dst, int32_t dtype, i
     const long long total = (long long)n * 2 * h * 2 * w * (c / N);
     const int blocks = (int)((total + 255) / 256 < 16384 ? (total + 255) / 256 : 16384);
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-    if (dtype == MNET_F16) hipLaunchKernelGGL(upsample2x_kernel<f16>, dim3(blocks), dim3(256), 0, st, (const f16*)src, (f16*)dst, h, w, c, total);
-    else hipLaunchKernelGGL(upsample2x_kernel<float>, dim3(blocks), dim3(256), 0, st, (const float*)src, (float*)dst, h, w, c, total);
+    if (dtype == MNET_F16) hipLaunchKernelGGL(upsample2x_kernel<f16>, dim3(blocks), dim3(256), 0, st, (const f16*)src, (f16*)dst, h, w, c, scale, total);
+    else hipLaunchKernelGGL(upsample2x_kernel<float>, dim3(blocks), dim3(256), 0, st, (const float*)src, (float*)dst, h, w, c, scale, total);
     MNET_LAUNCH_CHECK("upsample2x");
     return MNET_OK;
+}
+
+extern "C" int mnet_upsample2x_nhwc(const void* src, void* dst, int32_t dtype, int32_t n, int32_t h, int32_t w,
+                                    int32_t c, void* stream) {
+    return mnet_upsample2x_scale_nhwc(src, dst, dtype, n, h, w, c, nullptr, stream);
 }
 
 // ============================================================================ GroupNorm statistics -> affine
@@ -486,5 +497,44 @@ extern "C" int mnet_fused_bias_act(const float* x, const float* bias, float* y, 
     hipLaunchKernelGGL(fused_bias_act_kernel, dim3(blocks), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), x, bias, y,
                        (long long)total, C, inner, negative_slope, scale);
     MNET_LAUNCH_CHECK("fused_bias_act");
+    return MNET_OK;
+}
+
+// ============================================================================ per-(n,c) affine (+ swish), elementwise
+template <typename T>
+__global__ void __launch_bounds__(256) affine_act_kernel(const T* __restrict__ x, T* __restrict__ y, int HW, int C,
+                                                         const float* __restrict__ scale, const float* __restrict__ shift,
+                                                         int swish, long long total_chunks) {
+    constexpr int N = Vec<T>::N;
+    const int cpp = C / N;
+    for (long long id = (long long)blockIdx.x * blockDim.x + threadIdx.x; id < total_chunks;
+         id += (long long)gridDim.x * blockDim.x) {
+        const int ch = (int)(id % cpp);
+        const int n = (int)(id / ((long long)cpp * HW));
+        const size_t so = (size_t)n * C + (size_t)ch * N;
+        float v[N];
+        Vec<T>::unpack(ldg16(x + (size_t)id * N), v);
+#pragma unroll
+        for (int j = 0; j < N; ++j) {
+            float t = v[j] * scale[so + j] + (shift ? shift[so + j] : 0.f);
+            if (swish) t = t * (1.f / (1.f + expf(-t)));
+            v[j] = t;
+        }
+        stg16(y + (size_t)id * N, Vec<T>::pack(v));
+    }
+}
+
+extern "C" int mnet_affine_act_nhwc(const void* x, void* y, int32_t dtype, int32_t n, int32_t hw, int32_t c,
+                                    const float* scale, const float* shift, int32_t swish, void* stream) {
+    MNET_CHECK_ARG(x && y && scale && n > 0 && hw > 0 && c > 0, "affine_act: bad args");
+    MNET_CHECK_ARG(dtype == MNET_F32 || dtype == MNET_F16, "affine_act: bad dtype");
+    const int N = dtype == MNET_F16 ? 8 : 4;
+    MNET_CHECK_ALIGN(c % N == 0 && aligned16(x) && aligned16(y), "affine_act: unaligned");
+    const long long total = (long long)n * hw * (c / N);
+    const int blocks = (int)((total + 255) / 256 < 32768 ? (total + 255) / 256 : 32768);
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    if (dtype == MNET_F16) hipLaunchKernelGGL(affine_act_kernel<f16>, dim3(blocks), dim3(256), 0, st, (const f16*)x, (f16*)y, hw, c, scale, shift, swish, total);
+    else hipLaunchKernelGGL(affine_act_kernel<float>, dim3(blocks), dim3(256), 0, st, (const float*)x, (float*)y, hw, c, scale, shift, swish, total);
+    MNET_LAUNCH_CHECK("affine_act");
     return MNET_OK;
 }

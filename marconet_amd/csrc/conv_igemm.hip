@@ -23,7 +23,7 @@
 struct ConvArgs {
     const void* x0; const void* x1; const void* wgt; void* y; const void* res;
     const float* in_scale; const float* in_shift; const float* out_scale; const float* bias;
-    const int* valid_w;
+    const float* post_scale; const int* valid_w;
     int c0, c1, cin;
     int n, h, w, ho, wo, cout;
     int kh, kw, sh, sw, ph, pw;
@@ -213,7 +213,7 @@ __global__ void __launch_bounds__(256, 2) conv_igemm_kernel(const ConvArgs p) {
     for (int fb = 0; fb < FP; ++fb) {
         const int pix = pix0 + wp * (BP / WP) + fb * 16 + l16;
         if (pix >= p.npix) continue;
-        const int n = p.out_scale ? pix / p.howo : 0;
+        const int n = (p.out_scale || p.post_scale) ? pix / p.howo : 0;
         const int rpix = p.res_mod > 0 ? pix % p.res_mod : pix;
 #pragma unroll
         for (int fa = 0; fa < FC; ++fa) {
@@ -235,6 +235,7 @@ __global__ void __launch_bounds__(256, 2) conv_igemm_kernel(const ConvArgs p) {
                 v[0] = act_apply(v[0], p.act); v[1] = act_apply(v[1], p.act);
                 v[2] = act_apply(v[2], p.act); v[3] = act_apply(v[3], p.act);
             }
+            if (p.post_scale) v *= *reinterpret_cast<const f32x4*>(p.post_scale + (size_t)n * p.cout + co);
             T* yp = yo + (size_t)pix * p.cout + co;
             if constexpr (sizeof(T) == 4) {
                 *reinterpret_cast<f32x4*>(yp) = v;
@@ -299,13 +300,14 @@ extern "C" int mnet_conv2d_nhwc(const mnet_conv_desc* d, void* stream) {
     MNET_CHECK_ALIGN(d->cout % 4 == 0, "conv: cout=%d must be a multiple of 4", d->cout);
     MNET_CHECK_ALIGN(aligned16(d->x0) && aligned16(d->x1) && aligned16(d->wgt) && aligned16(d->y) &&
                      aligned16(d->residual) && aligned16(d->in_scale) && aligned16(d->in_shift) &&
-                     aligned16(d->out_scale) && aligned16(d->bias), "conv: pointers must be 16-byte aligned");
+                     aligned16(d->out_scale) && aligned16(d->bias) && aligned16(d->post_scale), "conv: pointers must be 16-byte aligned");
     const long long npix = (long long)d->n * d->ho * d->wo;
     MNET_CHECK_ARG(npix < (1ll << 31) && (long long)d->n * d->h * d->w < (1ll << 31), "conv: too many pixels");
 
     ConvArgs a;
     a.x0 = d->x0; a.x1 = d->x1; a.wgt = d->wgt; a.y = d->y; a.res = d->residual;
     a.in_scale = d->in_scale; a.in_shift = d->in_shift; a.out_scale = d->out_scale; a.bias = d->bias;
+    a.post_scale = d->post_scale;
     a.valid_w = d->valid_w;
     a.c0 = d->c0; a.c1 = d->c1; a.cin = d->c0 + d->c1;
     a.n = d->n; a.h = d->h; a.w = d->w; a.ho = d->ho; a.wo = d->wo; a.cout = d->cout;

@@ -186,13 +186,18 @@ class TextGenerator(nn.Module):
 
     # ------------------------------------------------------------------ forward pieces
     @staticmethod
-    def _styled(L, x, latent):
-        s = ops.linear(latent, L["mod_w"], L["cin"], bias=L["mod_b"])          # modulation EqualLinear (:283)
-        d = ops.demod(s, L["wsq_t"])                                           # rsqrt(Σ (scale·W·s)² + 1e-8) (:286)
-        if L["up"]:
-            x = ops.upsample2x(x)                                              # bilinear ×2 before the conv (:293)
-        return ops.conv2d(x, L["w"], L["cout"], 3, 3, (1, 1), (1, 1), in_scale=s, out_scale=d, bias=L["bias"],
-                          act=ops.ACT_LRELU_SQRT2)
+    def _style(L, latent):
+        """modulation EqualLinear (:283) and the demodulation table rsqrt(Σ (scale·W·s)² + 1e-8) (:286)"""
+        s = ops.linear(latent, L["mod_w"], L["cin"], bias=L["mod_b"])
+        return s, ops.demod(s, L["wsq_t"])
+
+    @staticmethod
+    def _styled(L, x, s, d, premodulated, post=None):
+        """StyledConv with activation-side modulation.  ``premodulated``: x already carries ·s (applied once per
+        element by the producer: the fused upsample or the previous conv's post_scale) — otherwise the conv
+        prologue applies it.  ``post``: the NEXT StyledConv's style, multiplied into this conv's output."""
+        return ops.conv2d(x, L["w"], L["cout"], 3, 3, (1, 1), (1, 1), in_scale=None if premodulated else s,
+                          out_scale=d, bias=L["bias"], act=ops.ACT_LRELU_SQRT2, post_scale=post)
 
     @staticmethod
     def _to_rgb(L, x, latent, skip):
@@ -209,13 +214,20 @@ class TextGenerator(nn.Module):
         for w, b in pk["mlp"]:
             lat = ops.linear(lat, w, self.style_dim, bias=b, act=ops.ACT_LRELU_SQRT2)
         x = ops.embed_gather(pk["emb"], labels, dtype, self.class_num)         # SelectText (:205-215)
-        x = self._styled(pk["conv1"], x, lat)
+        s, d = self._style(pk["conv1"], lat)
+        x = self._styled(pk["conv1"], x, s, d, premodulated=False)
         skip = self._to_rgb(pk["rgb1"], x, lat, None)
         p64 = p32 = None
         nc = labels.shape[1]
         for lvl in range(len(pk["rgbs"])):
-            x = self._styled(pk["convs"][2 * lvl], x, lat)
-            x = self._styled(pk["convs"][2 * lvl + 1], x, lat)
+            La, Lb = pk["convs"][2 * lvl], pk["convs"][2 * lvl + 1]
+            sa, da = self._style(La, lat)
+            sb, db = self._style(Lb, lat)
+            xu = ops.upsample2x(x, scale=sa)                                   # bilinear ×2 (:293) with ·s_a fused
+            xa = self._styled(La, xu, sa, da, premodulated=True, post=sb)      # emits x_a·s_b (x_a has no other reader)
+            del xu
+            x = self._styled(Lb, xa, sb, db, premodulated=True)
+            del xa
             skip = self._to_rgb(pk["rgbs"][lvl], x, lat, skip)
             if x.shape[2] == 64 * nc:
                 p64 = x
@@ -360,15 +372,19 @@ class TSPSRNet(nn.Module, _Precision):
         return self._c(pk, name + ".2", h, valid_w=valid_w)
 
     def _res_block(self, pk, name, x, valid_w=None):
-        """ResTextBlockV2 (networks.py:506-516): GN+swish ride in the conv prologue; skip (+1x1 conv_out) in the epilogue."""
+        """ResTextBlockV2 (networks.py:506-516): GN statistics → one elementwise normalise+swish pass → conv; the skip
+        (+1x1 conv_out) rides in the second conv's epilogue."""
         s1, h1 = ops.groupnorm_affine(x, *pk[name + ".norm1"], 1e-6, valid_w)
-        h = self._c(pk, name + ".conv1", x, valid_w=valid_w, in_scale=s1, in_shift=h1)
+        xs = ops.affine_act(x, s1, h1, swish=True)              # GN apply + swish once per element
+        h = self._c(pk, name + ".conv1", xs, valid_w=valid_w)
+        del xs
         s2, h2 = ops.groupnorm_affine(h, *pk[name + ".norm2"], 1e-6, valid_w)
+        ops.affine_act(h, s2, h2, swish=True, out=h)            # in place: h has no other reader
         skip = x
         if (name + ".conv_out") in pk:
             co = pk[name + ".conv_out"]
             skip = ops.conv2d(x, co["w"], co["b"].numel(), bias=co["b"])
-        return self._c(pk, name + ".conv2", h, valid_w=valid_w, in_scale=s2, in_shift=h2, residual=skip)
+        return self._c(pk, name + ".conv2", h, valid_w=valid_w, residual=skip)
 
     def _prior_transform(self, pk, tag, feat, prior, tab):
         """All glyphs of the batch at one scale (networks.py:421-449 / :455-482)."""
@@ -401,12 +417,24 @@ class TSPSRNet(nn.Module, _Precision):
 
     # ------------------------------------------------------------------ forward
     def forward(self, lq, priors64, priors32, locs):
+        """reference call form (test_sr.py:197): lists (one entry per image) of NCHW fp32 priors."""
         with torch.no_grad():
-            pk = self._cache.get(self, self.precision, self._build)
             dtype = torch_dtype(self.precision)
             B = lq.shape[0]
             if len(priors32) > B or len(priors64) > B:
                 raise IndexError("more prior lists (%d / %d) than images (%d)" % (len(priors64), len(priors32), B))
+            counts32 = [int(p.shape[0]) for p in priors32] + [0] * (B - len(priors32))
+            counts64 = [int(p.shape[0]) for p in priors64] + [0] * (B - len(priors64))
+            p32 = self._gather_priors(priors32, dtype, 512, 32) if sum(counts32) else None
+            p64 = self._gather_priors(priors64, dtype, 256, 64) if sum(counts64) else None
+            return ops.nhwc_to_nchw(self.forward_packed(lq, p64, p32, counts64, counts32, locs), c=3)
+
+    def forward_packed(self, lq, p64, p32, counts64, counts32, locs):
+        """batched entry: ``p64`` NHWC [ΣN,64,64,256] / ``p32`` NHWC [ΣN,32,32,512] hold the glyph priors of all
+        images back to back (``counts*[b]`` glyphs for image b).  Returns NHWC [B,128,2048,8] (RGB in channels 0-2)."""
+        with torch.no_grad():
+            pk = self._cache.get(self, self.precision, self._build)
+            dtype = torch_dtype(self.precision)
             x = ops.nchw_to_nhwc(lq.contiguous().float(), dtype, c_ld=8)
             f32 = self._c(pk, "conv_first_32.0", x, ops.ACT_LRELU)                               # :412
             f16 = self._c(pk, "conv_first_16.0", f32, ops.ACT_LRELU)                             # :413
@@ -416,13 +444,10 @@ class TSPSRNet(nn.Module, _Precision):
             del f8, f16, s16, f32, x
 
             # glyph windows: ONE device→host copy of locs, integer tables back
-            counts32 = [int(p.shape[0]) for p in priors32] + [0] * (B - len(priors32))
-            counts64 = [int(p.shape[0]) for p in priors64] + [0] * (B - len(priors64))
-            locs_host = locs.detach().float().cpu().numpy() if (sum(counts32) + sum(counts64)) else None
-            W32 = s32.shape[2]
-            tab32 = GlyphTables(locs_host, counts32[:B], W32, 16, lq.device) if sum(counts32) else None
-            if tab32 is not None:
-                p32 = self._gather_priors(priors32, dtype, 512, 32)
+            n32, n64 = sum(counts32), sum(counts64)
+            locs_host = locs.detach().float().cpu().numpy() if (n32 + n64) else None
+            if n32:
+                tab32 = GlyphTables(locs_host, counts32, s32.shape[2], 16, lq.device)
                 p32 = self._two(pk, "conv_32_to256", p32)                                        # :424
                 s32 = self._prior_transform(pk, "32", s32, p32, tab32)                           # :425-449
                 del p32
@@ -432,9 +457,8 @@ class TSPSRNet(nn.Module, _Precision):
             h = self._res_block(pk, "conv_up.3", h)
             s64 = self._c(pk, "conv_up.4", h)
             del h
-            tab64 = GlyphTables(locs_host, counts64[:B], s64.shape[2], 32, lq.device) if sum(counts64) else None
-            if tab64 is not None:
-                p64 = self._gather_priors(priors64, dtype, 256, 64)
+            if n64:
+                tab64 = GlyphTables(locs_host, counts64, s64.shape[2], 32, lq.device)
                 s64 = self._prior_transform(pk, "64", s64, p64, tab64)                           # :455-482
                 del p64
 
@@ -442,5 +466,4 @@ class TSPSRNet(nn.Module, _Precision):
             del s64
             h = self._c(pk, "conv_final.3", ops.upsample2x(h), ops.ACT_LRELU)
             h = self._res_block(pk, "conv_final.5", h)
-            out = self._c(pk, "conv_final.6", h, ops.ACT_TANH)
-            return ops.nhwc_to_nchw(out, c=3)
+            return self._c(pk, "conv_final.6", h, ops.ACT_TANH)

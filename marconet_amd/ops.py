@@ -11,7 +11,7 @@ from . import _lib
 from ._lib import (ACT_GELU, ACT_LRELU, ACT_LRELU_SQRT2, ACT_NONE, ACT_RELU, ACT_SIGMOID, ACT_TANH, MNET_F16,
                    MNET_F32, ConvDesc)
 
-__all__ = ["conv2d", "linear", "nchw_to_nhwc", "nhwc_to_nchw", "upsample2x", "groupnorm_affine",
+__all__ = ["conv2d", "linear", "nchw_to_nhwc", "nhwc_to_nchw", "upsample2x", "affine_act", "groupnorm_affine",
            "adain_crop_concat", "glyph_scatter_affine", "layernorm", "token_mix", "attention", "pixelnorm",
            "embed_gather", "demod", "argmax_rows", "convert", "fused_bias_act", "stats",
            "ACT_NONE", "ACT_RELU", "ACT_LRELU", "ACT_LRELU_SQRT2", "ACT_TANH", "ACT_GELU", "ACT_SIGMOID"]
@@ -63,10 +63,10 @@ stats = _Stats()
 
 def conv2d(x0, wgt, cout, kh=1, kw=1, stride=(1, 1), pad=(0, 0), x1=None, in_scale=None, in_shift=None,
            in_swish=False, valid_w=None, out_scale=None, bias=None, residual=None, res_mod=0, act=ACT_NONE,
-           out=None):
+           post_scale=None, out=None):
     """mnet_conv2d_nhwc.  x0 [N,H,W,C0] (+ optional x1 [N,H,W,C1]); wgt packed [cout,kh,kw,C0+C1] same dtype."""
     lib = _lib.load()
-    _need_cuda(x0, x1, wgt, in_scale, in_shift, valid_w, out_scale, bias, residual, out)
+    _need_cuda(x0, x1, wgt, in_scale, in_shift, valid_w, out_scale, bias, residual, post_scale, out)
     n, h, w, c0 = x0.shape
     c1 = 0 if x1 is None else x1.shape[3]
     if wgt.dtype != x0.dtype or wgt.numel() != cout * kh * kw * (c0 + c1):
@@ -94,8 +94,10 @@ def conv2d(x0, wgt, cout, kh=1, kw=1, stride=(1, 1), pad=(0, 0), x1=None, in_sca
     d.residual = None if residual is None else residual.data_ptr()
     d.res_mod = res_mod
     d.act = act
+    d.post_scale = None if post_scale is None else post_scale.data_ptr()
     d.y = out.data_ptr()
-    for t, nm in ((in_scale, "in_scale"), (in_shift, "in_shift"), (out_scale, "out_scale"), (bias, "bias")):
+    for t, nm in ((in_scale, "in_scale"), (in_shift, "in_shift"), (out_scale, "out_scale"), (bias, "bias"),
+                  (post_scale, "post_scale")):
         if t is not None and t.dtype != torch.float32:
             raise TypeError("conv2d: %s must be float32" % nm)
     if valid_w is not None and valid_w.dtype != torch.int32:
@@ -148,13 +150,26 @@ def nhwc_to_nchw(src, c=None):
     return dst
 
 
-def upsample2x(src):
+def upsample2x(src, scale=None):
+    """bilinear x2 (align_corners=False); optional per-(n,c) fp32 multiplier fused into the store"""
     lib = _lib.load()
-    _need_cuda(src)
+    _need_cuda(src, scale)
     n, h, w, c = src.shape
     dst = torch.empty((n, 2 * h, 2 * w, c), dtype=src.dtype, device=src.device)
-    _lib.check(lib.mnet_upsample2x_nhwc(_p(src), _p(dst), _dt(src), n, h, w, c, _stream()), "mnet_upsample2x_nhwc")
+    _lib.check(lib.mnet_upsample2x_scale_nhwc(_p(src), _p(dst), _dt(src), n, h, w, c, _p(scale), _stream()),
+               "mnet_upsample2x_scale_nhwc")
     return dst
+
+
+def affine_act(x, scale, shift=None, swish=False, out=None):
+    """y = f(x*scale[n,c] + shift[n,c]) elementwise over NHWC x [N,H,W,C] (GroupNorm apply + swish)."""
+    lib = _lib.load()
+    _need_cuda(x, scale, shift, out)
+    n, h, w, c = x.shape
+    y = torch.empty_like(x) if out is None else out
+    _lib.check(lib.mnet_affine_act_nhwc(_p(x), _p(y), _dt(x), n, h * w, c, _p(scale), _p(shift), 1 if swish else 0,
+                                        _stream()), "mnet_affine_act_nhwc")
+    return y
 
 
 def groupnorm_affine(x, gamma, beta, eps=1e-6, valid_w=None):

@@ -308,3 +308,27 @@ def test_gan_small_ops():
     h = ops.convert(xx.to(DEV), torch.float16)
     assert torch.equal(h.cpu(), xx.half())
     assert torch.equal(ops.convert(h, torch.float32).cpu(), xx.half().float())
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float16])
+def test_post_scale_upsample_scale_affine_act(dtype):
+    ops = _ops()
+    n, h, w, cin, cout = 3, 6, 10, 32, 40
+    x = _q(_rnd((n, cin, h, w), 50), dtype)
+    wt = _q(_rnd((cout, cin, 3, 3), 51, 1.0 / math.sqrt(cin * 9)), dtype)
+    bias, osc, post = _rnd((cout,), 52, 0.3), _rnd((n, cout), 53).abs() + 0.5, _rnd((n, cout), 54) + 1.0
+    ref = F.leaky_relu(F.conv2d(x, wt, padding=1) * osc[:, :, None, None] + bias[None, :, None, None], 0.2) * 2 ** 0.5
+    ref = ref * post[:, :, None, None]
+    y = ops.conv2d(_nhwc(x, dtype), _pack_w(wt, dtype), cout, 3, 3, (1, 1), (1, 1), out_scale=osc.to(DEV), bias=bias.to(DEV),
+                   act=ops.ACT_LRELU_SQRT2, post_scale=post.to(DEV))
+    _check("conv post_scale %s" % dtype, _nchw(y), ref, dtype, extra=2.0)
+    sc = _rnd((n, cin), 55) + 1.0
+    ref = F.interpolate(x, scale_factor=2, mode="bilinear", align_corners=False) * sc[:, :, None, None]
+    _check("upsample2x*scale %s" % dtype, _nchw(ops.upsample2x(_nhwc(x, dtype), scale=sc.to(DEV))), ref, dtype)
+    sh = _rnd((n, cin), 56, 0.3)
+    t = x * sc[:, :, None, None] + sh[:, :, None, None]
+    xd = _nhwc(x, dtype)
+    _check("affine_act swish %s" % dtype, _nchw(ops.affine_act(xd, sc.to(DEV), sh.to(DEV), swish=True)), t * torch.sigmoid(t), dtype)
+    _check("affine_act scale only %s" % dtype, _nchw(ops.affine_act(xd, sc.to(DEV))), x * sc[:, :, None, None], dtype)
+    ops.affine_act(xd, sc.to(DEV), sh.to(DEV), swish=True, out=xd)       # in place
+    _check("affine_act in-place %s" % dtype, _nchw(xd), t * torch.sigmoid(t), dtype)
