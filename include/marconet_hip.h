@@ -95,6 +95,11 @@ typedef struct {
 
 int mnet_conv2d_nhwc(const mnet_conv_desc* d, void* stream);
 
+/* same with an explicit kernel choice (A/B measurements, tests): AUTO picks the LDS-DMA kernel when the launch is
+ * eligible (f16, (c0+c1) % 64 == 0, c0 % 64 == 0, cout >= 64, no in_scale) and the register-staged one otherwise */
+enum { MNET_CONV_ALGO_AUTO = 0, MNET_CONV_ALGO_REG_STAGED = 1, MNET_CONV_ALGO_LDS_DMA = 2 };
+int mnet_conv2d_nhwc_ex(const mnet_conv_desc* d, int32_t algo, void* stream);
+
 /* 2*MACs of the launch described by d (for roofline accounting in bench.py) */
 double mnet_conv2d_flops(const mnet_conv_desc* d);
 

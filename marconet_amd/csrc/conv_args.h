@@ -1,0 +1,19 @@
+// Kernel-argument block shared by the two implicit-GEMM conv kernels (conv_igemm.hip, conv_igemm_dma.hip).
+#pragma once
+#include "common.h"
+
+struct ConvArgs {
+    const void* x0; const void* x1; const void* wgt; void* y; const void* res;
+    const float* in_scale; const float* in_shift; const float* out_scale; const float* bias;
+    const float* post_scale; const int* valid_w;
+    int c0, c1, cin;
+    int n, h, w, ho, wo, cout;
+    int kh, kw, sh, sw, ph, pw;
+    int K, npix, howo;
+    int in_swish, act, res_mod;
+    int ktiles, tilesC;
+};
+
+// conv_igemm_dma.hip
+bool conv_dma_eligible(const ConvArgs& a, int dtype);
+int launch_conv_dma(const ConvArgs& a, hipStream_t st);

@@ -19,18 +19,8 @@
 // Workgroup ids are remapped so that each XCD (private 4 MiB L2) owns a contiguous run of tiles and the
 // cout-tiles of one pixel tile are neighbours (the activation slab is then re-read from L2, not HBM).
 #include "common.h"
+#include "conv_args.h"
 
-struct ConvArgs {
-    const void* x0; const void* x1; const void* wgt; void* y; const void* res;
-    const float* in_scale; const float* in_shift; const float* out_scale; const float* bias;
-    const float* post_scale; const int* valid_w;
-    int c0, c1, cin;
-    int n, h, w, ho, wo, cout;
-    int kh, kw, sh, sw, ph, pw;
-    int K, npix, howo;
-    int in_swish, act, res_mod;
-    int ktiles, tilesC;
-};
 
 template <typename T> struct Mma;
 template <> struct Mma<f16> {
@@ -280,7 +270,8 @@ extern "C" double mnet_conv2d_flops(const mnet_conv_desc* d) {
     return 2.0 * (double)d->n * d->ho * d->wo * d->cout * (double)d->kh * d->kw * (d->c0 + d->c1);
 }
 
-extern "C" int mnet_conv2d_nhwc(const mnet_conv_desc* d, void* stream) {
+extern "C" int mnet_conv2d_nhwc_ex(const mnet_conv_desc* d, int32_t algo, void* stream) {
+    MNET_CHECK_ARG(algo >= 0 && algo <= 2, "conv: bad algo %d", algo);
     MNET_CHECK_ARG(d != nullptr, "conv: null descriptor");
     MNET_CHECK_ARG(d->dtype == MNET_F32 || d->dtype == MNET_F16, "conv: bad dtype %d", d->dtype);
     MNET_CHECK_ARG(d->x0 && d->wgt && d->y, "conv: null tensor pointer");
@@ -317,5 +308,13 @@ extern "C" int mnet_conv2d_nhwc(const mnet_conv_desc* d, void* stream) {
     const int bk = d->dtype == MNET_F16 ? 64 : 32;
     a.ktiles = (a.K + bk - 1) / bk; a.tilesC = 0;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    const bool dma_ok = conv_dma_eligible(a, d->dtype);
+    if (algo == MNET_CONV_ALGO_LDS_DMA && !dma_ok)
+        return mnet_fail(MNET_E_ARG, "conv: LDS-DMA algo needs f16, cin %% 64 == 0, cout >= 64 and no input transform");
+    if (dma_ok && algo != MNET_CONV_ALGO_REG_STAGED) return launch_conv_dma(a, st);
     return d->dtype == MNET_F16 ? launch_dtype<f16>(a, st) : launch_dtype<float>(a, st);
+}
+
+extern "C" int mnet_conv2d_nhwc(const mnet_conv_desc* d, void* stream) {
+    return mnet_conv2d_nhwc_ex(d, MNET_CONV_ALGO_AUTO, stream);
 }

@@ -1,0 +1,219 @@
+// Implicit-GEMM convolution, LDS-DMA variant (f16 storage, fp32 accumulate) — the fast path for every conv
+// whose input-channel count is a multiple of 64 and that needs no input-side transform.
+//
+// What differs from conv_igemm.hip (the general, register-staged kernel):
+//  * both operand tiles go HBM/L2 → LDS directly with `buffer_load_dwordx4 … lds` (1 KiB per wave-instruction):
+//    no VGPR round trip, no ds_write pass, ~40 fewer VGPRs.  Zero padding, ragged valid width, the cout tail
+//    and the pixel tail cost nothing: an invalid lane gets an out-of-range buffer offset and the hardware
+//    writes zeros into its LDS slot (raw buffer bounds check against num_records).
+//  * the 16-byte-chunk XOR swizzle of the LDS image is applied on the *source* side (lane (row, phys chunk)
+//    fetches logical chunk phys ^ ((row>>1)&7)), because an LDS-DMA destination is always lane-linear.
+//  * 8 waves per workgroup on a 256x128 / 128x256 / 64x256 (cout x pixel) tile, 64x64 (64x32) per wave;
+//    3-stage LDS ring (3 x 48 KiB), one raw s_barrier per 64-deep k-slab, counted `s_waitcnt vmcnt(N)` so the
+//    DMA of slab t+1 stays in flight across the barrier while slab t is multiplied (no vmcnt(0) in the loop).
+//  * with cin % 64 == 0 a k-slab never straddles a filter tap or the concat boundary, so tap (r,s), source
+//    tensor and channel offset are wave-uniform scalars advanced incrementally — no integer division in the loop.
+#include "common.h"
+#include "conv_args.h"
+
+typedef __attribute__((address_space(3))) void lds_void;
+
+__device__ __forceinline__ int swz_dma(int row, int chunk) { return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4); }
+
+#define VMCNT(n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
+
+template <int BC, int BP, int WC, int WP>
+__global__ void __launch_bounds__(512, 2) conv_dma_kernel(const ConvArgs p) {
+    constexpr int FC = BC / WC / 16, FP = BP / WP / 16;
+    constexpr int WJ = BC / 64, XJ = BP / 64;            // DMA instructions per wave per slab (weights / activations)
+    constexpr int NDMA = WJ + XJ;
+    constexpr int STAGE = (BC + BP) * 128;
+    constexpr unsigned OOB = 0x80000000u;                // beyond every num_records used below
+    static_assert(WC * WP == 8, "8 waves");
+    static_assert(NDMA == 6 || NDMA == 5, "vmcnt immediates below assume 5 or 6 DMAs per slab");
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wc = wave / WP, wp = wave % WP;
+    const int l16 = lane & 15, g = lane >> 4;
+
+    const int nwg = gridDim.x, bid = blockIdx.x;
+    const int q8 = nwg >> 3, r8 = nwg & 7, xcd = bid & 7;
+    const int wg = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
+    const int tc = wg % p.tilesC, tp = wg / p.tilesC;
+    const int co0 = tc * BC, pix0 = tp * BP;
+
+    // ---- buffer descriptors (wave-uniform).  Weights: rows co0.. ; bound = remaining rows → cout tail reads zeros.
+    const long long wbytes = (long long)(p.cout - co0) * p.K * 2;
+    const __amdgpu_buffer_rsrc_t rW = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)(reinterpret_cast<const f16*>(p.wgt) + (size_t)co0 * p.K), 0, (int)(wbytes < 0x7fffffffLL ? wbytes : 0x7fffffffLL), 0x00020000);
+    // Activations: base = first image touched by this pixel tile; bound = the images the tile can touch.
+    const int n_first = pix0 / p.howo;
+    int n_last = (min(pix0 + BP, p.npix) - 1) / p.howo;
+    const long long img0 = (long long)p.h * p.w * p.c0 * 2, img1 = (long long)p.h * p.w * p.c1 * 2;
+    const int nimg = n_last - n_first + 1;
+    const __amdgpu_buffer_rsrc_t rX0 = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)(reinterpret_cast<const char*>(p.x0) + (size_t)n_first * img0), 0, (int)(img0 * nimg), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rX1 = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)(p.x1 ? reinterpret_cast<const char*>(p.x1) + (size_t)n_first * img1 : reinterpret_cast<const char*>(p.x0)),
+        0, (int)(p.x1 ? img1 * nimg : 0), 0x00020000);
+
+    // ---- per-lane DMA geometry: lane (rg = lane/8, pc = lane%8) of wave w fills LDS rows (w + 8j)*8 + rg
+    const int rg = lane >> 3, pc = lane & 7;
+    unsigned woff[WJ];                                   // byte offset of this lane's weight chunk at k-slab 0
+#pragma unroll
+    for (int j = 0; j < WJ; ++j) {
+        const int row = (wave + 8 * j) * 8 + rg;
+        const int lc = pc ^ ((row >> 1) & 7);
+        woff[j] = (co0 + row < p.cout) ? (unsigned)(row * p.K * 2 + lc * 16) : OOB;
+    }
+    int xpix[XJ], xih[XJ], xiw[XJ], xvw[XJ], xlc[XJ];   // pixel index rel. to n_first, top-left tap coords, chunk
+#pragma unroll
+    for (int j = 0; j < XJ; ++j) {
+        const int row = (wave + 8 * j) * 8 + rg;
+        const int pix = pix0 + row;
+        xlc[j] = (pc ^ ((row >> 1) & 7)) * 16;
+        if (pix < p.npix) {
+            const int n = pix / p.howo, rem = pix - n * p.howo;
+            const int oh = rem / p.wo, ow = rem - oh * p.wo;
+            xih[j] = oh * p.sh - p.ph; xiw[j] = ow * p.sw - p.pw;
+            xpix[j] = ((n - n_first) * p.h + xih[j]) * p.w + xiw[j];
+            xvw[j] = p.valid_w ? min(p.valid_w[n], p.w) : p.w;
+        } else { xih[j] = 0; xiw[j] = 0; xpix[j] = 0; xvw[j] = 0; }   // xvw = 0 → never valid
+    }
+
+    // ---- wave-uniform k-slab cursor: filter tap (fr, fs) and channel offset inside the tap
+    int cur_c = 0, cur_r = 0, cur_s = 0, cur_k = 0;
+    auto issue_slab = [&](int stage) {
+        unsigned char* sw_ = smem + stage * STAGE;
+        unsigned char* sx_ = sw_ + BC * 128;
+        const unsigned kb = (unsigned)cur_k * 2u;
+#pragma unroll
+        for (int j = 0; j < WJ; ++j) {
+            const unsigned vo = woff[j] == OOB ? OOB : woff[j] + kb;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rW, (lds_void*)(sw_ + (wave + 8 * j) * 1024), 16, vo, 0, 0, 0);
+        }
+        const bool second = cur_c >= p.c0;              // uniform: which concat source this slab reads
+        const int cs2 = (second ? p.c1 : p.c0) * 2;      // bytes per pixel of that source
+        const int cb = (second ? cur_c - p.c0 : cur_c) * 2;
+        const int tap = cur_r * p.w + cur_s;
+#pragma unroll
+        for (int j = 0; j < XJ; ++j) {
+            const int ih = xih[j] + cur_r, iw = xiw[j] + cur_s;
+            const bool ok = (unsigned)ih < (unsigned)p.h && (unsigned)iw < (unsigned)xvw[j];
+            const unsigned vo = ok ? (unsigned)((xpix[j] + tap) * cs2 + cb + xlc[j]) : OOB;
+            if (second) __builtin_amdgcn_raw_ptr_buffer_load_lds(rX1, (lds_void*)(sx_ + (wave + 8 * j) * 1024), 16, vo, 0, 0, 0);
+            else __builtin_amdgcn_raw_ptr_buffer_load_lds(rX0, (lds_void*)(sx_ + (wave + 8 * j) * 1024), 16, vo, 0, 0, 0);
+        }
+        cur_k += 64; cur_c += 64;
+        if (cur_c == p.cin) { cur_c = 0; if (++cur_s == p.kw) { cur_s = 0; ++cur_r; } }
+    };
+
+    f32x4 acc[FC][FP];
+#pragma unroll
+    for (int a = 0; a < FC; ++a)
+#pragma unroll
+        for (int b = 0; b < FP; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    auto compute_slab = [&](int stage) {
+        const unsigned char* sw_ = smem + stage * STAGE;
+        const unsigned char* sx_ = sw_ + BC * 128;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            const int chunk = ks * 4 + g;
+            u32x4 a[FC], b[FP];
+#pragma unroll
+            for (int f = 0; f < FC; ++f) a[f] = *reinterpret_cast<const u32x4*>(sw_ + swz_dma(wc * (BC / WC) + f * 16 + l16, chunk));
+#pragma unroll
+            for (int f = 0; f < FP; ++f) b[f] = *reinterpret_cast<const u32x4*>(sx_ + swz_dma(wp * (BP / WP) + f * 16 + l16, chunk));
+#pragma unroll
+            for (int fa = 0; fa < FC; ++fa)
+#pragma unroll
+                for (int fb = 0; fb < FP; ++fb)
+                    acc[fa][fb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bitcast<f16x8>(a[fa]), bitcast<f16x8>(b[fb]), acc[fa][fb], 0, 0, 0);
+        }
+    };
+
+    // ---- 3-stage ring: slabs t+1 (and t+2 once issued) stay in flight across the barrier of slab t
+    const int nk = p.ktiles;
+    issue_slab(0);
+    if (nk > 1) issue_slab(1);
+    int st_c = 0, st_i = 2;           // stage being computed / stage being filled next
+    for (int kt = 0; kt < nk; ++kt) {
+        if (kt + 1 < nk) { if constexpr (NDMA == 6) VMCNT(6); else VMCNT(5); }    // slab kt landed (this wave's DMAs)
+        else VMCNT(0);
+        __builtin_amdgcn_s_barrier();                                             // …everyone's; stage st_i is free
+        asm volatile("" ::: "memory");
+        if (kt + 2 < nk) issue_slab(st_i);
+        compute_slab(st_c);
+        st_c = st_c == 2 ? 0 : st_c + 1;
+        st_i = st_i == 2 ? 0 : st_i + 1;
+    }
+
+    // ---- epilogue (identical math to conv_igemm.hip)
+    f16* yo = reinterpret_cast<f16*>(p.y);
+    const f16* rs = reinterpret_cast<const f16*>(p.res);
+#pragma unroll
+    for (int fb = 0; fb < FP; ++fb) {
+        const int pix = pix0 + wp * (BP / WP) + fb * 16 + l16;
+        if (pix >= p.npix) continue;
+        const int n = (p.out_scale || p.post_scale) ? pix / p.howo : 0;
+        const int rpix = p.res_mod > 0 ? pix % p.res_mod : pix;
+#pragma unroll
+        for (int fa = 0; fa < FC; ++fa) {
+            const int co = co0 + wc * (BC / WC) + fa * 16 + g * 4;
+            if (co >= p.cout) continue;
+            f32x4 v = acc[fa][fb];
+            if (p.out_scale) v *= *reinterpret_cast<const f32x4*>(p.out_scale + (size_t)n * p.cout + co);
+            if (p.bias) v += *reinterpret_cast<const f32x4*>(p.bias + co);
+            if (rs) {
+                const f16x4 r4 = *reinterpret_cast<const f16x4*>(rs + (size_t)rpix * p.cout + co);
+                v[0] += (float)r4[0]; v[1] += (float)r4[1]; v[2] += (float)r4[2]; v[3] += (float)r4[3];
+            }
+            if (p.act != MNET_ACT_NONE) {
+                v[0] = act_apply(v[0], p.act); v[1] = act_apply(v[1], p.act);
+                v[2] = act_apply(v[2], p.act); v[3] = act_apply(v[3], p.act);
+            }
+            if (p.post_scale) v *= *reinterpret_cast<const f32x4*>(p.post_scale + (size_t)n * p.cout + co);
+            const f16x4 o4 = {(f16)v[0], (f16)v[1], (f16)v[2], (f16)v[3]};
+            *reinterpret_cast<f16x4*>(yo + (size_t)pix * p.cout + co) = o4;
+        }
+    }
+}
+
+template <int BC, int BP, int WC, int WP>
+static int launch_dma_cfg(const ConvArgs& a, hipStream_t st) {
+    constexpr int LDS = 3 * (BC + BP) * 128;
+    auto kern = conv_dma_kernel<BC, BP, WC, WP>;
+    static thread_local bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+        if (e != hipSuccess) return mnet_fail(MNET_E_LAUNCH, "hipFuncSetAttribute(dma): %s", hipGetErrorString(e));
+        attr_set = true;
+    }
+    ConvArgs b = a;
+    b.tilesC = (a.cout + BC - 1) / BC;
+    const int tilesP = (a.npix + BP - 1) / BP;
+    hipLaunchKernelGGL(kern, dim3((unsigned)(b.tilesC * tilesP)), dim3(512), LDS, st, b);
+    MNET_LAUNCH_CHECK("conv_dma_kernel");
+    return MNET_OK;
+}
+
+// eligibility of the LDS-DMA path (see header comment); the caller falls back to the register-staged kernel
+bool conv_dma_eligible(const ConvArgs& a, int dtype) {
+    if (dtype != MNET_F16 || a.in_scale) return false;
+    if (a.cin % 64 != 0 || a.c0 % 64 != 0 || a.cout < 64) return false;
+    // 31-bit buffer offsets: a pixel tile may touch ceil(256/howo)+1 images
+    const long long imgs = 256 / a.howo + 2;
+    const long long per_img = (long long)a.h * a.w * (a.c0 > a.c1 ? a.c0 : a.c1) * 2;
+    if (per_img * imgs >= 0x7fffffffLL) return false;
+    if ((long long)256 * a.K * 2 >= 0x40000000LL) return false;
+    return true;
+}
+
+int launch_conv_dma(const ConvArgs& a, hipStream_t st) {
+    if (a.cout >= 256) return launch_dma_cfg<256, 128, 4, 2>(a, st);
+    if (a.cout >= 128) return launch_dma_cfg<128, 256, 2, 4>(a, st);
+    return launch_dma_cfg<64, 256, 1, 8>(a, st);
+}

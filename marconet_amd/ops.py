@@ -63,8 +63,8 @@ stats = _Stats()
 
 def conv2d(x0, wgt, cout, kh=1, kw=1, stride=(1, 1), pad=(0, 0), x1=None, in_scale=None, in_shift=None,
            in_swish=False, valid_w=None, out_scale=None, bias=None, residual=None, res_mod=0, act=ACT_NONE,
-           post_scale=None, out=None):
-    """mnet_conv2d_nhwc.  x0 [N,H,W,C0] (+ optional x1 [N,H,W,C1]); wgt packed [cout,kh,kw,C0+C1] same dtype."""
+           post_scale=None, out=None, algo=0):
+    """mnet_conv2d_nhwc(_ex).  x0 [N,H,W,C0] (+ optional x1 [N,H,W,C1]); wgt packed [cout,kh,kw,C0+C1] same dtype."""
     lib = _lib.load()
     _need_cuda(x0, x1, wgt, in_scale, in_shift, valid_w, out_scale, bias, residual, post_scale, out)
     n, h, w, c0 = x0.shape
@@ -112,11 +112,11 @@ def conv2d(x0, wgt, cout, kh=1, kw=1, stride=(1, 1), pad=(0, 0), x1=None, in_sca
             s = torch.cuda.Event(enable_timing=True)
             e = torch.cuda.Event(enable_timing=True)
             s.record()
-            _lib.check(lib.mnet_conv2d_nhwc(ctypes.byref(d), _stream()), "mnet_conv2d_nhwc")
+            _lib.check(lib.mnet_conv2d_nhwc_ex(ctypes.byref(d), algo, _stream()), "mnet_conv2d_nhwc")
             e.record()
             stats.events.append((s, e, fl, d.dtype))
             return out
-    _lib.check(lib.mnet_conv2d_nhwc(ctypes.byref(d), _stream()), "mnet_conv2d_nhwc")
+    _lib.check(lib.mnet_conv2d_nhwc_ex(ctypes.byref(d), algo, _stream()), "mnet_conv2d_nhwc")
     return out
 
 

@@ -332,3 +332,58 @@ def test_post_scale_upsample_scale_affine_act(dtype):
     _check("affine_act scale only %s" % dtype, _nchw(ops.affine_act(xd, sc.to(DEV))), x * sc[:, :, None, None], dtype)
     ops.affine_act(xd, sc.to(DEV), sh.to(DEV), swish=True, out=xd)       # in place
     _check("affine_act in-place %s" % dtype, _nchw(xd), t * torch.sigmoid(t), dtype)
+
+
+DMA_CASES = [
+    # n, h, w, c0, c1, cout, k, stride, pad
+    (2, 9, 13, 64, 0, 256, 3, (1, 1), 1),
+    (3, 16, 24, 128, 0, 128, 3, (1, 1), 1),
+    (2, 12, 20, 64, 0, 64, 3, (2, 1), 1),
+    (2, 12, 20, 128, 0, 320, 3, (2, 2), 1),
+    (5, 8, 8, 192, 0, 136, 1, (1, 1), 0),
+    (2, 8, 16, 256, 128, 256, 3, (1, 1), 1),
+    (2, 8, 16, 256, 64, 256, 3, (1, 1), 1),
+    (40, 4, 4, 512, 0, 512, 3, (1, 1), 1),
+    (1, 32, 512, 64, 0, 64, 3, (1, 1), 1),
+]
+
+
+@pytest.mark.parametrize("case", DMA_CASES)
+def test_conv_lds_dma_kernel(case):
+    """the LDS-DMA fast path: against F.conv2d and bit-for-bit against the register-staged kernel
+    (same k order and MFMA shape → identical fp32 accumulation)."""
+    ops = _ops()
+    dtype = torch.float16
+    n, h, w, c0, c1, cout, k, stride, pad = case
+    x = _q(_rnd((n, c0 + c1, h, w), 61), dtype)
+    wt = _q(_rnd((cout, c0 + c1, k, k), 62, 1.0 / math.sqrt((c0 + c1) * k * k)), dtype)
+    bias = _rnd((cout,), 63, 0.3)
+    osc, post = _rnd((n, cout), 64).abs() + 0.5, _rnd((n, cout), 65) + 1.0
+    ho = (h + 2 * pad - k) // stride[0] + 1
+    wo = (w + 2 * pad - k) // stride[1] + 1
+    res = _q(_rnd((n, cout, ho, wo), 66), dtype)
+    vw = torch.tensor([w - (i % 3) * 2 for i in range(n)], dtype=torch.int32)
+    refs = []
+    for i in range(n):
+        xi = x[i:i + 1].clone()
+        xi[..., int(vw[i]):] = 0
+        refs.append(F.conv2d(xi, wt, stride=stride, padding=pad))
+    ref = F.leaky_relu(torch.cat(refs) * osc[:, :, None, None] + bias[None, :, None, None] + res, 0.2) * post[:, :, None, None]
+    x0 = _nhwc(x[:, :c0], dtype)
+    x1 = _nhwc(x[:, c0:], dtype) if c1 else None
+    kw = dict(x1=x1, valid_w=vw.to(DEV), out_scale=osc.to(DEV), bias=bias.to(DEV), residual=_nhwc(res, dtype),
+              act=ops.ACT_LRELU, post_scale=post.to(DEV))
+    y_dma = ops.conv2d(x0, _pack_w(wt, dtype), cout, k, k, stride, (pad, pad), algo=2, **kw)
+    y_reg = ops.conv2d(x0, _pack_w(wt, dtype), cout, k, k, stride, (pad, pad), algo=1, **kw)
+    torch.cuda.synchronize()
+    _check("conv LDS-DMA %s" % (case,), _nchw(y_dma), ref, dtype, extra=2.0)
+    assert torch.equal(y_dma, y_reg), "LDS-DMA and register-staged kernels must agree bit for bit"
+
+
+def test_conv_lds_dma_eligibility():
+    ops = _ops()
+    from marconet_amd._lib import MarconetHipError
+    x = torch.zeros(1, 4, 4, 32, dtype=torch.float16, device=DEV)
+    w = torch.zeros(64, 3, 3, 32, dtype=torch.float16, device=DEV)
+    with pytest.raises(MarconetHipError):
+        ops.conv2d(x, w, 64, 3, 3, (1, 1), (1, 1), algo=2)        # cin % 64 != 0

@@ -1,0 +1,57 @@
+#!/usr/bin/env python
+"""A/B micro-benchmark of the two implicit-GEMM conv kernels on representative MARCONet layer shapes
+(interleaved rounds in one process, median of HIP-event timings).  python tools/conv_bench.py [--rounds 7]"""
+import argparse
+import os
+import sys
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+SHAPES = [  # name, n, h, w, c0, c1, cout, k
+    ("sr_trunk_64x1024_256", 16, 64, 1024, 256, 0, 256, 3),
+    ("sr_glyph64_512to256", 256, 64, 64, 512, 0, 256, 3),
+    ("sr_glyph64_256", 256, 64, 64, 256, 0, 256, 3),
+    ("gan_32_512", 256, 32, 32, 512, 0, 512, 3),
+    ("gan_128_256to128", 128, 128, 128, 256, 0, 128, 3),
+    ("gan_128_128", 128, 128, 128, 128, 0, 128, 3),
+    ("resnet_l5_512", 64, 8, 512, 512, 0, 512, 3),
+    ("resnet_l5_1x1", 64, 8, 512, 512, 0, 512, 1),
+    ("sr_body32_cat", 64, 32, 512, 256, 64, 256, 3),
+    ("sr_final_128to64", 16, 128, 2048, 128, 0, 64, 3),
+    ("sr_final_64", 16, 128, 2048, 64, 0, 64, 3),
+]
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--rounds", type=int, default=5)
+    a = ap.parse_args()
+    from marconet_amd import ops
+    dev = "cuda"
+    print("%-26s %10s %10s %8s" % ("shape", "reg TF/s", "dma TF/s", "speedup"))
+    for name, n, h, w, c0, c1, cout, k in SHAPES:
+        g = torch.Generator(device=dev).manual_seed(1)
+        x0 = (torch.rand((n, h, w, c0), device=dev, generator=g) - 0.5).half()
+        x1 = (torch.rand((n, h, w, c1), device=dev, generator=g) - 0.5).half() if c1 else None
+        wt = ((torch.rand((cout, k, k, c0 + c1), device=dev, generator=g) - 0.5) * 0.05).half()
+        bias = torch.zeros(cout, device=dev)
+        flops = 2.0 * n * h * w * cout * k * k * (c0 + c1)
+        t = {1: [], 2: []}
+        for r in range(a.rounds + 1):
+            for algo in (1, 2):
+                s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                s.record()
+                y = ops.conv2d(x0, wt, cout, k, k, (1, 1), (k // 2, k // 2), x1=x1, bias=bias, act=ops.ACT_LRELU, algo=algo)
+                e.record()
+                torch.cuda.synchronize()
+                if r:
+                    t[algo].append(s.elapsed_time(e))
+        m1, m2 = sorted(t[1])[len(t[1]) // 2], sorted(t[2])[len(t[2]) // 2]
+        print("%-26s %10.1f %10.1f %8.2fx" % (name, flops / m1 / 1e9, flops / m2 / 1e9, m1 / m2))
+
+
+if __name__ == "__main__":
+    main()
