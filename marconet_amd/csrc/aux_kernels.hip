@@ -79,50 +79,55 @@ extern "C" int mnet_nhwc_to_nchw(const void* src, int32_t src_dtype, float* dst,
 template <typename T>
 __global__ void __launch_bounds__(256) upsample2x_kernel(const T* __restrict__ src, T* __restrict__ dst,
                                                          int H, int W, int C, const float* __restrict__ scale,
-                                                         long long total_chunks) {
+                                                         unsigned chunks_per_image) {
+    // grid: x strides over the 16-byte chunks of ONE output image (32-bit index math only), y = image
     constexpr int N = Vec<T>::N;
-    const int cpp = C / N;     // chunks per pixel
-    for (long long id = (long long)blockIdx.x * blockDim.x + threadIdx.x; id < total_chunks;
-         id += (long long)gridDim.x * blockDim.x) {
-        const int ch = (int)(id % cpp);
-        long long pix = id / cpp;
-        const int ox = (int)(pix % (2 * W)); pix /= (2 * W);
-        const int oy = (int)(pix % (2 * H));
-        const int n = (int)(pix / (2 * H));
+    const unsigned cpp = (unsigned)C / N;
+    const int n = blockIdx.y;
+    const unsigned W2 = 2u * W;
+    const T* sbase = src + (size_t)n * H * W * C;
+    T* dbase = dst + (size_t)n * 4 * H * W * C;
+    for (unsigned id = blockIdx.x * 256u + threadIdx.x; id < chunks_per_image; id += gridDim.x * 256u) {
+        const unsigned ch = id % cpp, pix = id / cpp;
+        const int ox = (int)(pix % W2), oy = (int)(pix / W2);
         const int jy = oy >> 1, jx = ox >> 1;
         int y0, y1, x0, x1; float wy0, wy1, wx0, wx1;
         if (oy & 1) { y0 = jy; y1 = min(jy + 1, H - 1); wy0 = 0.75f; wy1 = 0.25f; }
         else { y0 = max(jy - 1, 0); y1 = jy; wy0 = 0.25f; wy1 = 0.75f; }
         if (ox & 1) { x0 = jx; x1 = min(jx + 1, W - 1); wx0 = 0.75f; wx1 = 0.25f; }
         else { x0 = max(jx - 1, 0); x1 = jx; wx0 = 0.25f; wx1 = 0.75f; }
-        const T* base = src + (size_t)n * H * W * C + (size_t)ch * N;
+        const T* base = sbase + (size_t)ch * N;
         float a[N], b[N], c[N], d[N], o[N];
-        Vec<T>::unpack(ldg16(base + ((size_t)y0 * W + x0) * C), a);
-        Vec<T>::unpack(ldg16(base + ((size_t)y0 * W + x1) * C), b);
-        Vec<T>::unpack(ldg16(base + ((size_t)y1 * W + x0) * C), c);
-        Vec<T>::unpack(ldg16(base + ((size_t)y1 * W + x1) * C), d);
+        Vec<T>::unpack(ldg16(base + (size_t)(y0 * W + x0) * C), a);
+        Vec<T>::unpack(ldg16(base + (size_t)(y0 * W + x1) * C), b);
+        Vec<T>::unpack(ldg16(base + (size_t)(y1 * W + x0) * C), c);
+        Vec<T>::unpack(ldg16(base + (size_t)(y1 * W + x1) * C), d);
 #pragma unroll
         for (int j = 0; j < N; ++j) o[j] = wy0 * (wx0 * a[j] + wx1 * b[j]) + wy1 * (wx0 * c[j] + wx1 * d[j]);
         if (scale) {
             const float* sp = scale + (size_t)n * C + (size_t)ch * N;
 #pragma unroll
-            for (int j = 0; j < N; ++j) o[j] *= sp[j];
+            for (int j = 0; j < N; j += 4) {
+                const f32x4 s4 = *reinterpret_cast<const f32x4*>(sp + j);
+                o[j] *= s4[0]; o[j + 1] *= s4[1]; o[j + 2] *= s4[2]; o[j + 3] *= s4[3];
+            }
         }
-        stg16(dst + (size_t)id * N, Vec<T>::pack(o));
+        stg16(dbase + (size_t)id * N, Vec<T>::pack(o));
     }
 }
 
 extern "C" int mnet_upsample2x_scale_nhwc(const void* src, void* dst, int32_t dtype, int32_t n, int32_t h, int32_t w,
                                           int32_t c, const float* scale, void* stream) {
-    MNET_CHECK_ARG(src && dst && n > 0 && h > 0 && w > 0 && c > 0, "upsample2x: bad args");
+    MNET_CHECK_ARG(src && dst && n > 0 && h > 0 && w > 0 && c > 0 && n <= 65535, "upsample2x: bad args");
     MNET_CHECK_ARG(dtype == MNET_F32 || dtype == MNET_F16, "upsample2x: bad dtype");
     const int N = dtype == MNET_F16 ? 8 : 4;
-    MNET_CHECK_ALIGN(c % N == 0 && aligned16(src) && aligned16(dst), "upsample2x: c %% %d != 0 or unaligned", N);
-    const long long total = (long long)n * 2 * h * 2 * w * (c / N);
-    const int blocks = (int)((total + 255) / 256 < 16384 ? (total + 255) / 256 : 16384);
+    MNET_CHECK_ALIGN(c % N == 0 && aligned16(src) && aligned16(dst) && aligned16(scale), "upsample2x: c %% %d != 0 or unaligned", N);
+    const long long per = (long long)4 * h * w * (c / N);
+    MNET_CHECK_ARG(per < (1ll << 31), "upsample2x: image too large");
+    const int gx = (int)((per + 255) / 256 < 2048 ? (per + 255) / 256 : 2048);
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-    if (dtype == MNET_F16) hipLaunchKernelGGL(upsample2x_kernel<f16>, dim3(blocks), dim3(256), 0, st, (const f16*)src, (f16*)dst, h, w, c, scale, total);
-    else hipLaunchKernelGGL(upsample2x_kernel<float>, dim3(blocks), dim3(256), 0, st, (const float*)src, (float*)dst, h, w, c, scale, total);
+    if (dtype == MNET_F16) hipLaunchKernelGGL(upsample2x_kernel<f16>, dim3(gx, n), dim3(256), 0, st, (const f16*)src, (f16*)dst, h, w, c, scale, (unsigned)per);
+    else hipLaunchKernelGGL(upsample2x_kernel<float>, dim3(gx, n), dim3(256), 0, st, (const float*)src, (float*)dst, h, w, c, scale, (unsigned)per);
     MNET_LAUNCH_CHECK("upsample2x");
     return MNET_OK;
 }
@@ -501,40 +506,55 @@ extern "C" int mnet_fused_bias_act(const float* x, const float* bias, float* y, 
 }
 
 // ============================================================================ per-(n,c) affine (+ swish), elementwise
+// grid: x strides over the chunks of ONE image with a stride that is a multiple of chunks-per-pixel, so a thread
+// always lands on the same channel chunk: its 2x8 scale/shift values are loaded once, outside the loop.
 template <typename T>
-__global__ void __launch_bounds__(256) affine_act_kernel(const T* __restrict__ x, T* __restrict__ y, int HW, int C,
+__global__ void __launch_bounds__(256) affine_act_kernel(const T* __restrict__ x, T* __restrict__ y, int C,
                                                          const float* __restrict__ scale, const float* __restrict__ shift,
-                                                         int swish, long long total_chunks) {
+                                                         int swish, unsigned chunks_per_image) {
     constexpr int N = Vec<T>::N;
-    const int cpp = C / N;
-    for (long long id = (long long)blockIdx.x * blockDim.x + threadIdx.x; id < total_chunks;
-         id += (long long)gridDim.x * blockDim.x) {
-        const int ch = (int)(id % cpp);
-        const int n = (int)(id / ((long long)cpp * HW));
-        const size_t so = (size_t)n * C + (size_t)ch * N;
+    const unsigned cpp = (unsigned)C / N;
+    const int n = blockIdx.y;
+    const unsigned first = blockIdx.x * 256u + threadIdx.x;
+    const unsigned ch = first % cpp;
+    float sc[N], sh[N];
+    const size_t so = (size_t)n * C + (size_t)ch * N;
+#pragma unroll
+    for (int j = 0; j < N; j += 4) {
+        const f32x4 a4 = *reinterpret_cast<const f32x4*>(scale + so + j);
+        f32x4 b4 = {0.f, 0.f, 0.f, 0.f};
+        if (shift) b4 = *reinterpret_cast<const f32x4*>(shift + so + j);
+        sc[j] = a4[0]; sc[j + 1] = a4[1]; sc[j + 2] = a4[2]; sc[j + 3] = a4[3];
+        sh[j] = b4[0]; sh[j + 1] = b4[1]; sh[j + 2] = b4[2]; sh[j + 3] = b4[3];
+    }
+    const T* xb = x + (size_t)n * chunks_per_image * N;
+    T* yb = y + (size_t)n * chunks_per_image * N;
+    for (unsigned id = first; id < chunks_per_image; id += gridDim.x * 256u) {      // stride % cpp == 0 (host)
         float v[N];
-        Vec<T>::unpack(ldg16(x + (size_t)id * N), v);
+        Vec<T>::unpack(ldg16(xb + (size_t)id * N), v);
 #pragma unroll
         for (int j = 0; j < N; ++j) {
-            float t = v[j] * scale[so + j] + (shift ? shift[so + j] : 0.f);
-            if (swish) t = t * (1.f / (1.f + expf(-t)));
+            float t = v[j] * sc[j] + sh[j];
+            if (swish) t = t * __builtin_amdgcn_rcpf(1.f + __expf(-t));       // v_exp_f32 / v_rcp_f32: ~1 ulp each
             v[j] = t;
         }
-        stg16(y + (size_t)id * N, Vec<T>::pack(v));
+        stg16(yb + (size_t)id * N, Vec<T>::pack(v));
     }
 }
 
 extern "C" int mnet_affine_act_nhwc(const void* x, void* y, int32_t dtype, int32_t n, int32_t hw, int32_t c,
                                     const float* scale, const float* shift, int32_t swish, void* stream) {
-    MNET_CHECK_ARG(x && y && scale && n > 0 && hw > 0 && c > 0, "affine_act: bad args");
+    MNET_CHECK_ARG(x && y && scale && n > 0 && hw > 0 && c > 0 && n <= 65535, "affine_act: bad args");
     MNET_CHECK_ARG(dtype == MNET_F32 || dtype == MNET_F16, "affine_act: bad dtype");
     const int N = dtype == MNET_F16 ? 8 : 4;
-    MNET_CHECK_ALIGN(c % N == 0 && aligned16(x) && aligned16(y), "affine_act: unaligned");
-    const long long total = (long long)n * hw * (c / N);
-    const int blocks = (int)((total + 255) / 256 < 32768 ? (total + 255) / 256 : 32768);
+    MNET_CHECK_ALIGN(c % N == 0 && 256 % (c / N) == 0 && aligned16(x) && aligned16(y) && aligned16(scale) && aligned16(shift),
+                     "affine_act: c=%d unsupported or unaligned", c);
+    const long long per = (long long)hw * (c / N);
+    MNET_CHECK_ARG(per < (1ll << 31), "affine_act: image too large");
+    const int gx = (int)((per + 255) / 256 < 1024 ? (per + 255) / 256 : 1024);
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-    if (dtype == MNET_F16) hipLaunchKernelGGL(affine_act_kernel<f16>, dim3(blocks), dim3(256), 0, st, (const f16*)x, (f16*)y, hw, c, scale, shift, swish, total);
-    else hipLaunchKernelGGL(affine_act_kernel<float>, dim3(blocks), dim3(256), 0, st, (const float*)x, (float*)y, hw, c, scale, shift, swish, total);
+    if (dtype == MNET_F16) hipLaunchKernelGGL(affine_act_kernel<f16>, dim3(gx, n), dim3(256), 0, st, (const f16*)x, (f16*)y, c, scale, shift, swish, (unsigned)per);
+    else hipLaunchKernelGGL(affine_act_kernel<float>, dim3(gx, n), dim3(256), 0, st, (const float*)x, (float*)y, c, scale, shift, swish, (unsigned)per);
     MNET_LAUNCH_CHECK("affine_act");
     return MNET_OK;
 }

@@ -13,6 +13,7 @@
 //    DMA of slab t+1 stays in flight across the barrier while slab t is multiplied (no vmcnt(0) in the loop).
 //  * with cin % 64 == 0 a k-slab never straddles a filter tap or the concat boundary, so tap (r,s), source
 //    tensor and channel offset are wave-uniform scalars advanced incrementally — no integer division in the loop.
+#include <cstdlib>
 #include "common.h"
 #include "conv_args.h"
 
@@ -22,15 +23,17 @@ __device__ __forceinline__ int swz_dma(int row, int chunk) { return row * 128 + 
 
 #define VMCNT(n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
 
-template <int BC, int BP, int WC, int WP>
-__global__ void __launch_bounds__(512, 2) conv_dma_kernel(const ConvArgs p) {
+template <int BC, int BP, int WC, int WP, int STAGES>
+__global__ void __launch_bounds__(WC * WP * 64, WC * WP / 4) conv_dma_kernel(const ConvArgs p) {
+    constexpr int NW = WC * WP;                          // waves per workgroup (8 or 16)
     constexpr int FC = BC / WC / 16, FP = BP / WP / 16;
-    constexpr int WJ = BC / 64, XJ = BP / 64;            // DMA instructions per wave per slab (weights / activations)
+    constexpr int WJ = BC / (8 * NW), XJ = BP / (8 * NW); // DMA instructions per wave per slab (weights / activations)
     constexpr int NDMA = WJ + XJ;
     constexpr int STAGE = (BC + BP) * 128;
     constexpr unsigned OOB = 0x80000000u;                // beyond every num_records used below
-    static_assert(WC * WP == 8, "8 waves");
-    static_assert(NDMA == 6 || NDMA == 5, "vmcnt immediates below assume 5 or 6 DMAs per slab");
+    static_assert(NW == 8 || NW == 16, "8 or 16 waves");
+    static_assert(WJ >= 1 && XJ >= 1 && WJ * 8 * NW == BC && XJ * 8 * NW == BP, "tile / wave-count mismatch");
+    static_assert(STAGES == 2 || (STAGES == 3 && (NDMA == 6 || NDMA == 5)), "vmcnt immediates below assume 5 or 6 DMAs per slab");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 
     const int tid = threadIdx.x, lane = tid & 63;
@@ -64,50 +67,71 @@ __global__ void __launch_bounds__(512, 2) conv_dma_kernel(const ConvArgs p) {
     unsigned woff[WJ];                                   // byte offset of this lane's weight chunk at k-slab 0
 #pragma unroll
     for (int j = 0; j < WJ; ++j) {
-        const int row = (wave + 8 * j) * 8 + rg;
+        const int row = (wave + NW * j) * 8 + rg;
         const int lc = pc ^ ((row >> 1) & 7);
         woff[j] = (co0 + row < p.cout) ? (unsigned)(row * p.K * 2 + lc * 16) : OOB;
     }
-    int xpix[XJ], xih[XJ], xiw[XJ], xvw[XJ], xlc[XJ];   // pixel index rel. to n_first, top-left tap coords, chunk
+    // activation rows: byte offset of (tap (0,0), channel 0) in each concat source, and a bit mask of the filter taps
+    // whose input pixel exists (inside the image and left of valid_w) — kh*kw <= 32 on this path
+    unsigned xb0[XJ], xb1[XJ], xmask[XJ];
 #pragma unroll
     for (int j = 0; j < XJ; ++j) {
-        const int row = (wave + 8 * j) * 8 + rg;
+        const int row = (wave + NW * j) * 8 + rg;
         const int pix = pix0 + row;
-        xlc[j] = (pc ^ ((row >> 1) & 7)) * 16;
+        const int lcb = (pc ^ ((row >> 1) & 7)) * 16;
+        xb0[j] = 0; xb1[j] = 0; xmask[j] = 0;
         if (pix < p.npix) {
             const int n = pix / p.howo, rem = pix - n * p.howo;
             const int oh = rem / p.wo, ow = rem - oh * p.wo;
-            xih[j] = oh * p.sh - p.ph; xiw[j] = ow * p.sw - p.pw;
-            xpix[j] = ((n - n_first) * p.h + xih[j]) * p.w + xiw[j];
-            xvw[j] = p.valid_w ? min(p.valid_w[n], p.w) : p.w;
-        } else { xih[j] = 0; xiw[j] = 0; xpix[j] = 0; xvw[j] = 0; }   // xvw = 0 → never valid
+            const int ih0 = oh * p.sh - p.ph, iw0 = ow * p.sw - p.pw;
+            const int px = ((n - n_first) * p.h + ih0) * p.w + iw0;
+            const int vw = p.valid_w ? min(p.valid_w[n], p.w) : p.w;
+            xb0[j] = (unsigned)(px * p.c0 * 2 + lcb);
+            xb1[j] = (unsigned)(px * p.c1 * 2 + lcb);
+            // taps enumerated t = r*kw + q; fixed 8-trip loops (kh, kw <= 8) so everything stays in registers
+            unsigned cm = 0, m = 0;
+#pragma unroll
+            for (int q = 0; q < 8; ++q)
+                if (q < p.kw && (unsigned)(iw0 + q) < (unsigned)vw) cm |= 1u << q;
+#pragma unroll
+            for (int r = 0; r < 8; ++r)
+                if (r < p.kh && (unsigned)(ih0 + r) < (unsigned)p.h) m |= cm << (r * p.kw);
+            xmask[j] = m;
+        }
     }
 
-    // ---- wave-uniform k-slab cursor: filter tap (fr, fs) and channel offset inside the tap
-    int cur_c = 0, cur_r = 0, cur_s = 0, cur_k = 0;
-    auto issue_slab = [&](int stage) {
+    // ---- wave-uniform k-slab cursor: filter tap index, channel offset inside the tap, tap pixel offset
+    int cur_c = 0, cur_s = 0, cur_tap = 0, cur_tpx = 0, cur_k = 0;
+    auto issue_slab = [&](int stage) __attribute__((always_inline)) {
         unsigned char* sw_ = smem + stage * STAGE;
         unsigned char* sx_ = sw_ + BC * 128;
         const unsigned kb = (unsigned)cur_k * 2u;
 #pragma unroll
         for (int j = 0; j < WJ; ++j) {
             const unsigned vo = woff[j] == OOB ? OOB : woff[j] + kb;
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rW, (lds_void*)(sw_ + (wave + 8 * j) * 1024), 16, vo, 0, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rW, (lds_void*)(sw_ + (wave + NW * j) * 1024), 16, vo, 0, 0, 0);
         }
-        const bool second = cur_c >= p.c0;              // uniform: which concat source this slab reads
-        const int cs2 = (second ? p.c1 : p.c0) * 2;      // bytes per pixel of that source
-        const int cb = (second ? cur_c - p.c0 : cur_c) * 2;
-        const int tap = cur_r * p.w + cur_s;
+        const unsigned tapbit = 1u << cur_tap;
+        if (cur_c >= p.c0) {                             // wave-uniform: second concat source
+            const unsigned uni = (unsigned)(cur_tpx * p.c1 * 2 + (cur_c - p.c0) * 2);
 #pragma unroll
-        for (int j = 0; j < XJ; ++j) {
-            const int ih = xih[j] + cur_r, iw = xiw[j] + cur_s;
-            const bool ok = (unsigned)ih < (unsigned)p.h && (unsigned)iw < (unsigned)xvw[j];
-            const unsigned vo = ok ? (unsigned)((xpix[j] + tap) * cs2 + cb + xlc[j]) : OOB;
-            if (second) __builtin_amdgcn_raw_ptr_buffer_load_lds(rX1, (lds_void*)(sx_ + (wave + 8 * j) * 1024), 16, vo, 0, 0, 0);
-            else __builtin_amdgcn_raw_ptr_buffer_load_lds(rX0, (lds_void*)(sx_ + (wave + 8 * j) * 1024), 16, vo, 0, 0, 0);
+            for (int j = 0; j < XJ; ++j) {
+                const unsigned vo = (xmask[j] & tapbit) ? xb1[j] + uni : OOB;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rX1, (lds_void*)(sx_ + (wave + NW * j) * 1024), 16, vo, 0, 0, 0);
+            }
+        } else {
+            const unsigned uni = (unsigned)(cur_tpx * p.c0 * 2 + cur_c * 2);
+#pragma unroll
+            for (int j = 0; j < XJ; ++j) {
+                const unsigned vo = (xmask[j] & tapbit) ? xb0[j] + uni : OOB;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rX0, (lds_void*)(sx_ + (wave + NW * j) * 1024), 16, vo, 0, 0, 0);
+            }
         }
         cur_k += 64; cur_c += 64;
-        if (cur_c == p.cin) { cur_c = 0; if (++cur_s == p.kw) { cur_s = 0; ++cur_r; } }
+        if (cur_c == p.cin) {
+            cur_c = 0; ++cur_tap;
+            if (++cur_s == p.kw) { cur_s = 0; cur_tpx += p.w - (p.kw - 1); } else { ++cur_tpx; }
+        }
     };
 
     f32x4 acc[FC][FP];
@@ -116,11 +140,10 @@ __global__ void __launch_bounds__(512, 2) conv_dma_kernel(const ConvArgs p) {
 #pragma unroll
         for (int b = 0; b < FP; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    auto compute_slab = [&](int stage) {
+    auto compute_half = [&](int stage, int ks) __attribute__((always_inline)) {
         const unsigned char* sw_ = smem + stage * STAGE;
         const unsigned char* sx_ = sw_ + BC * 128;
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
+        {
             const int chunk = ks * 4 + g;
             u32x4 a[FC], b[FP];
 #pragma unroll
@@ -135,20 +158,35 @@ __global__ void __launch_bounds__(512, 2) conv_dma_kernel(const ConvArgs p) {
         }
     };
 
-    // ---- 3-stage ring: slabs t+1 (and t+2 once issued) stay in flight across the barrier of slab t
     const int nk = p.ktiles;
-    issue_slab(0);
-    if (nk > 1) issue_slab(1);
-    int st_c = 0, st_i = 2;           // stage being computed / stage being filled next
-    for (int kt = 0; kt < nk; ++kt) {
-        if (kt + 1 < nk) { if constexpr (NDMA == 6) VMCNT(6); else VMCNT(5); }    // slab kt landed (this wave's DMAs)
-        else VMCNT(0);
-        __builtin_amdgcn_s_barrier();                                             // …everyone's; stage st_i is free
-        asm volatile("" ::: "memory");
-        if (kt + 2 < nk) issue_slab(st_i);
-        compute_slab(st_c);
-        st_c = st_c == 2 ? 0 : st_c + 1;
-        st_i = st_i == 2 ? 0 : st_i + 1;
+    if constexpr (STAGES == 3) {
+        // ---- 3-stage ring: slab t+1 stays in flight across the barrier of slab t (counted vmcnt, never 0 in the loop)
+        issue_slab(0);
+        if (nk > 1) issue_slab(1);
+        int st_c = 0, st_i = 2;           // stage being computed / stage being filled next
+        for (int kt = 0; kt < nk; ++kt) {
+            if (kt + 1 < nk) { if constexpr (NDMA == 6) VMCNT(6); else VMCNT(5); }    // slab kt landed (this wave's DMAs)
+            else VMCNT(0);
+            __builtin_amdgcn_s_barrier();                                             // …everyone's; stage st_i is free
+            asm volatile("" ::: "memory");
+            if (kt + 2 < nk) issue_slab(st_i);
+            compute_half(st_c, 0);
+            compute_half(st_c, 1);
+            st_c = st_c == 2 ? 0 : st_c + 1;
+            st_i = st_i == 2 ? 0 : st_i + 1;
+        }
+    } else {
+        // ---- 2-stage (256x256 tile, 16 waves): the DMA of slab t+1 is issued right after the barrier and overlaps the
+        // whole multiply of slab t (4 waves per SIMD x 32 MFMAs each); drained with vmcnt(0) just before the next barrier
+        issue_slab(0);
+        for (int kt = 0; kt < nk; ++kt) {
+            VMCNT(0);
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            if (kt + 1 < nk) issue_slab((kt + 1) & 1);
+            compute_half(kt & 1, 0);
+            compute_half(kt & 1, 1);
+        }
     }
 
     // ---- epilogue (identical math to conv_igemm.hip)
@@ -182,10 +220,10 @@ __global__ void __launch_bounds__(512, 2) conv_dma_kernel(const ConvArgs p) {
     }
 }
 
-template <int BC, int BP, int WC, int WP>
+template <int BC, int BP, int WC, int WP, int STAGES>
 static int launch_dma_cfg(const ConvArgs& a, hipStream_t st) {
-    constexpr int LDS = 3 * (BC + BP) * 128;
-    auto kern = conv_dma_kernel<BC, BP, WC, WP>;
+    constexpr int LDS = STAGES * (BC + BP) * 128;
+    auto kern = conv_dma_kernel<BC, BP, WC, WP, STAGES>;
     static thread_local bool attr_set = false;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
@@ -195,7 +233,7 @@ static int launch_dma_cfg(const ConvArgs& a, hipStream_t st) {
     ConvArgs b = a;
     b.tilesC = (a.cout + BC - 1) / BC;
     const int tilesP = (a.npix + BP - 1) / BP;
-    hipLaunchKernelGGL(kern, dim3((unsigned)(b.tilesC * tilesP)), dim3(512), LDS, st, b);
+    hipLaunchKernelGGL(kern, dim3((unsigned)(b.tilesC * tilesP)), dim3(WC * WP * 64), LDS, st, b);
     MNET_LAUNCH_CHECK("conv_dma_kernel");
     return MNET_OK;
 }
@@ -203,9 +241,9 @@ static int launch_dma_cfg(const ConvArgs& a, hipStream_t st) {
 // eligibility of the LDS-DMA path (see header comment); the caller falls back to the register-staged kernel
 bool conv_dma_eligible(const ConvArgs& a, int dtype) {
     if (dtype != MNET_F16 || a.in_scale) return false;
-    if (a.cin % 64 != 0 || a.c0 % 64 != 0 || a.cout < 64) return false;
+    if (a.cin % 64 != 0 || a.c0 % 64 != 0 || a.cout < 64 || a.kh * a.kw > 32 || a.kh > 8 || a.kw > 8) return false;
     // 31-bit buffer offsets: a pixel tile may touch ceil(256/howo)+1 images
-    const long long imgs = 256 / a.howo + 2;
+    const long long imgs = 256 / a.howo + 2;   // largest pixel tile is 256
     const long long per_img = (long long)a.h * a.w * (a.c0 > a.c1 ? a.c0 : a.c1) * 2;
     if (per_img * imgs >= 0x7fffffffLL) return false;
     if ((long long)256 * a.K * 2 >= 0x40000000LL) return false;
@@ -213,7 +251,11 @@ bool conv_dma_eligible(const ConvArgs& a, int dtype) {
 }
 
 int launch_conv_dma(const ConvArgs& a, hipStream_t st) {
-    if (a.cout >= 256) return launch_dma_cfg<256, 128, 4, 2>(a, st);
-    if (a.cout >= 128) return launch_dma_cfg<128, 256, 2, 4>(a, st);
-    return launch_dma_cfg<64, 256, 1, 8>(a, st);
+    static const int big = [] { const char* e = getenv("MNET_DMA_256"); return e ? atoi(e) : 1; }();   // tuning knob
+    if (a.cout >= 256) {
+        if (big && a.npix >= 256 * 256) return launch_dma_cfg<256, 256, 4, 4, 2>(a, st);
+        return launch_dma_cfg<256, 128, 4, 2, 3>(a, st);
+    }
+    if (a.cout >= 128) return launch_dma_cfg<128, 256, 2, 4, 3>(a, st);
+    return launch_dma_cfg<64, 256, 1, 8, 3>(a, st);
 }

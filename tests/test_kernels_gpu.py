@@ -345,6 +345,8 @@ DMA_CASES = [
     (2, 8, 16, 256, 64, 256, 3, (1, 1), 1),
     (40, 4, 4, 512, 0, 512, 3, (1, 1), 1),
     (1, 32, 512, 64, 0, 64, 3, (1, 1), 1),
+    (5, 120, 130, 64, 0, 320, 3, (1, 1), 1),       # npix >= 65536 and cout >= 256 → 256x256-tile, 16-wave variant
+    (70, 31, 33, 64, 64, 256, 3, (1, 1), 1),
 ]
 
 

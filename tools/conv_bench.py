@@ -28,11 +28,16 @@ SHAPES = [  # name, n, h, w, c0, c1, cout, k
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--rounds", type=int, default=5)
+    ap.add_argument("--algos", default="1,2")
+    ap.add_argument("--only", default="", help="comma-separated substrings of shape names")
     a = ap.parse_args()
     from marconet_amd import ops
     dev = "cuda"
     print("%-26s %10s %10s %8s" % ("shape", "reg TF/s", "dma TF/s", "speedup"))
+    algos = [int(v) for v in a.algos.split(",")]
     for name, n, h, w, c0, c1, cout, k in SHAPES:
+        if a.only and not any(o in name for o in a.only.split(",")):
+            continue
         g = torch.Generator(device=dev).manual_seed(1)
         x0 = (torch.rand((n, h, w, c0), device=dev, generator=g) - 0.5).half()
         x1 = (torch.rand((n, h, w, c1), device=dev, generator=g) - 0.5).half() if c1 else None
@@ -41,7 +46,7 @@ def main():
         flops = 2.0 * n * h * w * cout * k * k * (c0 + c1)
         t = {1: [], 2: []}
         for r in range(a.rounds + 1):
-            for algo in (1, 2):
+            for algo in algos:
                 s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 s.record()
                 y = ops.conv2d(x0, wt, cout, k, k, (1, 1), (k // 2, k // 2), x1=x1, bias=bias, act=ops.ACT_LRELU, algo=algo)
@@ -49,7 +54,8 @@ def main():
                 torch.cuda.synchronize()
                 if r:
                     t[algo].append(s.elapsed_time(e))
-        m1, m2 = sorted(t[1])[len(t[1]) // 2], sorted(t[2])[len(t[2]) // 2]
+        med = lambda v: sorted(v)[len(v) // 2] if v else float("nan")
+        m1, m2 = med(t[1]), med(t[2])
         print("%-26s %10.1f %10.1f %8.2fx" % (name, flops / m1 / 1e9, flops / m2 / 1e9, m1 / m2))
 
 
