@@ -1,0 +1,73 @@
+"""N>1 path of the data-parallel driver on CPU: world_size-2 ``gloo`` processes exercise the
+image sharding and the one collective of the path (all-gather of SR outputs), including uneven shards.  On the
+GPU node the same code runs with backend 'nccl' (= RCCL over xGMI); only the process-group backend differs."""
+import os
+import socket
+import sys
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _fake_sr(idx):
+    """stand-in for the per-image SR output: a deterministic function of the GLOBAL image index only"""
+    g = torch.Generator().manual_seed(1000 + int(idx))
+    return torch.rand((3, 8, 32), generator=g)
+
+
+def _worker(rank, world, port, total, out_q):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from marconet_amd.pipeline import all_gather_outputs, shard_range
+        a, b = shard_range(total, rank, world)
+        local = torch.stack([_fake_sr(i) for i in range(a, b)]) if b > a else torch.zeros((0, 3, 8, 32))
+        full = all_gather_outputs(local, total)
+        want = torch.stack([_fake_sr(i) for i in range(total)])
+        out_q.put((rank, tuple(full.shape), bool(torch.equal(full, want)), (a, b)))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("total", [8, 7, 3])
+def test_all_gather_outputs_world2_gloo(total):
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, total, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    ranges = sorted(r[3] for r in res)
+    assert ranges[0][0] == 0 and ranges[-1][1] == total and ranges[0][1] == ranges[1][0]      # contiguous cover
+    for rank, shape, equal, _ in res:
+        assert shape == (total, 3, 8, 32), (rank, shape)
+        assert equal, "rank %d: gathered outputs differ from the 1-process result" % rank
+
+
+def test_shard_range_partitions_exactly():
+    from marconet_amd.pipeline import shard_range
+    for total in (0, 1, 5, 64, 1024, 1027):
+        for world in (1, 2, 4, 8):
+            spans = [shard_range(total, r, world) for r in range(world)]
+            assert spans[0][0] == 0 and spans[-1][1] == total
+            assert all(spans[i][1] == spans[i + 1][0] for i in range(world - 1))
+            sizes = [b - a for a, b in spans]
+            assert max(sizes) - min(sizes) <= 1
