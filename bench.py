@@ -102,26 +102,53 @@ def main():
         dt = float(t.item())
     assert torch.isfinite(y).all()
 
-    # ---- roofline of the dominant kernel (f16 implicit-GEMM conv), from the live HIP events of the timed steps
-    f16_ms = sum(s.elapsed_time(e) for s, e, _, d in ops.stats.events if d == 1)
-    f16_launches = sum(1 for ev in ops.stats.events if ev[3] == 1)
-    f16_flops_launched = sum(fl for _, _, fl, d in ops.stats.events if d == 1)
-    f32_ms = sum(s.elapsed_time(e) for s, e, _, d in ops.stats.events if d == 0)
-    alg_gf_step = B * (GF_F16_FIXED + GF_F16_PER_GLYPH * n)           # algorithmic GFLOP of the f16 convs per step
+    # ---- roofline of the dominant kernel, from the live HIP events of the timed steps (events are recorded on the
+    # launch stream around every conv launch; the kernel each launch resolved to comes from mnet_conv2d_plan)
+    KNAME = {1: "conv_igemm_kernel (register-staged)", 16: "conv_dma_kernel<256,256,4,4,2>", 17: "conv_dma_kernel<256,128,4,2,3>",
+             18: "conv_dma_kernel<128,256,2,4,3>", 19: "conv_dma_kernel<64,256,1,8,3>", 20: "conv_dma_kernel<128,512,2,8,2>",
+             21: "conv_dma_kernel<64,512,1,8,2>"}
+    per = {}
+    for s_, e_, fl, dt_, kid in ops.stats.events:
+        key = (kid, dt_)
+        ms = s_.elapsed_time(e_)
+        r = per.setdefault(key, [0.0, 0.0, 0])
+        r[0] += ms; r[1] += fl; r[2] += 1
     prec16 = a.precision == "fp16"
-    dom_ms = (f16_ms if prec16 else f16_ms + f32_ms) / max(a.steps, 1)
-    achieved = alg_gf_step / max(dom_ms, 1e-9)                         # GFLOP/ms == TFLOP/s
+    cand = {k: v for k, v in per.items() if k[1] == (1 if prec16 else 0)}
+    dom = max(cand, key=lambda k: cand[k][0])
+    dom_ms, dom_fl, dom_n = cand[dom]
+    f16_ms = sum(v[0] for k, v in per.items() if k[1] == 1)
+    f32_ms = sum(v[0] for k, v in per.items() if k[1] == 0)
+    f16_n = sum(v[2] for k, v in per.items() if k[1] == 1)
+    f16_fl = sum(v[1] for k, v in per.items() if k[1] == 1)
+    alg_gf_step = B * (GF_F16_FIXED + GF_F16_PER_GLYPH * n)           # algorithmic GFLOP of the f16 convs per step
     peak = PEAK_F16_TFLOPS if prec16 else 157.3
+    achieved = dom_fl / max(dom_ms, 1e-9) / 1e9                        # FLOP/ms/1e9 == TFLOP/s
+    conv_ms = (f16_ms if prec16 else f16_ms + f32_ms) / max(a.steps, 1)
+    traffic = None
+    tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")        # measured separately (rocprofv3 --pmc), see DESIGN.md
+    if os.path.isfile(tpath):
+        try:
+            traffic = json.load(open(tpath)).get(KNAME.get(dom[0], ""), {}).get("hbm_bytes_per_launch")
+        except Exception:
+            traffic = None
     roofline = {
         "bound": "mfma", "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
-        "frac": round(achieved / peak, 4), "traffic": None,
-        "kernel": "conv_igemm_kernel<f16> (all tile configs)" if prec16 else "conv_igemm_kernel<float>",
-        "launches_per_step": f16_launches // max(a.steps, 1),
-        "avg_launch_ms": round(dom_ms / max(f16_launches // max(a.steps, 1), 1), 4),
-        "kernel_ms_per_step": round(dom_ms, 3),
-        "algorithmic_gflop_per_step": round(alg_gf_step, 1),
-        "launched_gflop_per_step": round(f16_flops_launched / max(a.steps, 1) / 1e9, 1),
-        "fp32_vit_gemm_ms_per_step": round(f32_ms / max(a.steps, 1), 3),
+        "frac": round(achieved / peak, 4), "traffic": traffic,
+        "kernel": KNAME.get(dom[0], str(dom[0])) + (" f16" if dom[1] == 1 else " f32"),
+        "launches_per_step": dom_n // max(a.steps, 1),
+        "avg_launch_ms": round(dom_ms / max(dom_n, 1), 4),
+        "flops_per_launch_avg": round(dom_fl / max(dom_n, 1), 1),
+        "kernel_ms_per_step": round(dom_ms / max(a.steps, 1), 3),
+        "all_conv_kernels": {
+            "achieved": round(alg_gf_step / max(conv_ms, 1e-9), 2), "frac": round(alg_gf_step / max(conv_ms, 1e-9) / peak, 4),
+            "launches_per_step": f16_n // max(a.steps, 1), "ms_per_step": round(conv_ms, 3),
+            "algorithmic_gflop_per_step": round(alg_gf_step, 1),
+            "launched_gflop_per_step": round(f16_fl / max(a.steps, 1) / 1e9, 1),
+            "by_kernel_ms_per_step": {KNAME.get(k[0], str(k[0])) + (" f16" if k[1] else " f32"): round(v[0] / max(a.steps, 1), 3)
+                                      for k, v in sorted(per.items())},
+        },
+        "end_to_end_frac_of_peak": None,
     }
 
     out = {
@@ -136,6 +163,7 @@ def main():
                    "parallelism": "dp%d" % world, "collective": "all_gather(SR outputs)" if world > 1 and not a.no_gather else "none"},
         "roofline": roofline,
     }
+    roofline["end_to_end_frac_of_peak"] = round(out["value"] / world * (GF_F16_FIXED + GF_F16_PER_GLYPH * n + GF_FP32_VIT) / 1e3 / peak, 4)
 
     # ---- CPU baseline (the oracle = port of the reference's CPU forward) + parity, rank 0 at N=1 only
     if rank == 0 and world == 1 and a.cpu_images > 0:

@@ -96,9 +96,15 @@ typedef struct {
 int mnet_conv2d_nhwc(const mnet_conv_desc* d, void* stream);
 
 /* same with an explicit kernel choice (A/B measurements, tests): AUTO picks the LDS-DMA kernel when the launch is
- * eligible (f16, (c0+c1) % 64 == 0, c0 % 64 == 0, cout >= 64, no in_scale) and the register-staged one otherwise */
-enum { MNET_CONV_ALGO_AUTO = 0, MNET_CONV_ALGO_REG_STAGED = 1, MNET_CONV_ALGO_LDS_DMA = 2 };
+ * eligible (f16, (c0+c1) % 64 == 0, c0 % 64 == 0, cout >= 64, cout % 8 == 0, no in_scale) and the register-staged
+ * one otherwise; MNET_CONV_ALGO_DMA_CFG0 + id pins one LDS-DMA tile configuration (cout x pixel tile, waves, stages):
+ *   id 0: 256x256 16w 2st   1: 256x128 8w 3st   2: 128x256 8w 3st   3: 64x256 8w 3st   4: 128x512 16w 2st   5: 64x512 8w 2st */
+enum { MNET_CONV_ALGO_AUTO = 0, MNET_CONV_ALGO_REG_STAGED = 1, MNET_CONV_ALGO_LDS_DMA = 2, MNET_CONV_ALGO_DMA_CFG0 = 16 };
 int mnet_conv2d_nhwc_ex(const mnet_conv_desc* d, int32_t algo, void* stream);
+
+/* which kernel `algo` resolves to for this launch, without launching: MNET_CONV_ALGO_REG_STAGED or
+ * MNET_CONV_ALGO_DMA_CFG0 + id; negative MNET_E_* on invalid arguments (bench.py buckets its timings by this) */
+int mnet_conv2d_plan(const mnet_conv_desc* d, int32_t algo);
 
 /* 2*MACs of the launch described by d (for roofline accounting in bench.py) */
 double mnet_conv2d_flops(const mnet_conv_desc* d);

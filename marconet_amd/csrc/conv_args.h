@@ -16,4 +16,5 @@ struct ConvArgs {
 
 // conv_igemm_dma.hip
 bool conv_dma_eligible(const ConvArgs& a, int dtype);
-int launch_conv_dma(const ConvArgs& a, hipStream_t st);
+int conv_dma_pick(const ConvArgs& a);                           // tile configuration id AUTO would use
+int launch_conv_dma(const ConvArgs& a, hipStream_t st, int cfg);   // cfg < 0: conv_dma_pick

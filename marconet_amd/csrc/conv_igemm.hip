@@ -270,8 +270,10 @@ extern "C" double mnet_conv2d_flops(const mnet_conv_desc* d) {
     return 2.0 * (double)d->n * d->ho * d->wo * d->cout * (double)d->kh * d->kw * (d->c0 + d->c1);
 }
 
-extern "C" int mnet_conv2d_nhwc_ex(const mnet_conv_desc* d, int32_t algo, void* stream) {
-    MNET_CHECK_ARG(algo >= 0 && algo <= 2, "conv: bad algo %d", algo);
+// argument validation shared by the launch and the planning entry points; fills the kernel-argument block
+static int conv_prepare(const mnet_conv_desc* d, int32_t algo, ConvArgs& a) {
+    MNET_CHECK_ARG((algo >= 0 && algo <= 2) || (algo >= MNET_CONV_ALGO_DMA_CFG0 && algo < MNET_CONV_ALGO_DMA_CFG0 + 16),
+                   "conv: bad algo %d", algo);
     MNET_CHECK_ARG(d != nullptr, "conv: null descriptor");
     MNET_CHECK_ARG(d->dtype == MNET_F32 || d->dtype == MNET_F16, "conv: bad dtype %d", d->dtype);
     MNET_CHECK_ARG(d->x0 && d->wgt && d->y, "conv: null tensor pointer");
@@ -295,7 +297,6 @@ extern "C" int mnet_conv2d_nhwc_ex(const mnet_conv_desc* d, int32_t algo, void* 
     const long long npix = (long long)d->n * d->ho * d->wo;
     MNET_CHECK_ARG(npix < (1ll << 31) && (long long)d->n * d->h * d->w < (1ll << 31), "conv: too many pixels");
 
-    ConvArgs a;
     a.x0 = d->x0; a.x1 = d->x1; a.wgt = d->wgt; a.y = d->y; a.res = d->residual;
     a.in_scale = d->in_scale; a.in_shift = d->in_shift; a.out_scale = d->out_scale; a.bias = d->bias;
     a.post_scale = d->post_scale;
@@ -307,11 +308,34 @@ extern "C" int mnet_conv2d_nhwc_ex(const mnet_conv_desc* d, int32_t algo, void* 
     a.in_swish = d->in_swish; a.act = d->act; a.res_mod = d->res_mod;
     const int bk = d->dtype == MNET_F16 ? 64 : 32;
     a.ktiles = (a.K + bk - 1) / bk; a.tilesC = 0;
-    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    return MNET_OK;
+}
+
+// resolves `algo` to the kernel that runs: MNET_CONV_ALGO_REG_STAGED or MNET_CONV_ALGO_DMA_CFG0 + id (negative: error)
+static int conv_resolve(const mnet_conv_desc* d, int32_t algo, const ConvArgs& a) {
     const bool dma_ok = conv_dma_eligible(a, d->dtype);
-    if (algo == MNET_CONV_ALGO_LDS_DMA && !dma_ok)
-        return mnet_fail(MNET_E_ARG, "conv: LDS-DMA algo needs f16, cin %% 64 == 0, cout >= 64 and no input transform");
-    if (dma_ok && algo != MNET_CONV_ALGO_REG_STAGED) return launch_conv_dma(a, st);
+    if (algo >= MNET_CONV_ALGO_LDS_DMA && !dma_ok)
+        return mnet_fail(MNET_E_ARG, "conv: LDS-DMA algo needs f16, cin %% 64 == 0, cout >= 64, cout %% 8 == 0 and no input transform");
+    if (algo >= MNET_CONV_ALGO_DMA_CFG0) return algo;
+    if (dma_ok && algo != MNET_CONV_ALGO_REG_STAGED) return MNET_CONV_ALGO_DMA_CFG0 + conv_dma_pick(a);
+    return MNET_CONV_ALGO_REG_STAGED;
+}
+
+extern "C" int mnet_conv2d_plan(const mnet_conv_desc* d, int32_t algo) {
+    ConvArgs a;
+    const int rc = conv_prepare(d, algo, a);
+    if (rc != MNET_OK) return rc;
+    return conv_resolve(d, algo, a);
+}
+
+extern "C" int mnet_conv2d_nhwc_ex(const mnet_conv_desc* d, int32_t algo, void* stream) {
+    ConvArgs a;
+    const int rc = conv_prepare(d, algo, a);
+    if (rc != MNET_OK) return rc;
+    const int k = conv_resolve(d, algo, a);
+    if (k < 0) return k;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    if (k >= MNET_CONV_ALGO_DMA_CFG0) return launch_conv_dma(a, st, k - MNET_CONV_ALGO_DMA_CFG0);
     return d->dtype == MNET_F16 ? launch_dtype<f16>(a, st) : launch_dtype<float>(a, st);
 }
 

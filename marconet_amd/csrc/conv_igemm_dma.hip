@@ -64,12 +64,17 @@ __global__ void __launch_bounds__(WC * WP * 64, WC * WP / 4) conv_dma_kernel(con
 
     // ---- per-lane DMA geometry: lane (rg = lane/8, pc = lane%8) of wave w fills LDS rows (w + 8j)*8 + rg
     const int rg = lane >> 3, pc = lane & 7;
+    // Weight rows are permuted on their way into LDS (free: the DMA source address is per lane) so that the two MFMA
+    // fragments 2t, 2t+1 of a lane together hold 8 CONSECUTIVE output channels → 16-byte epilogue loads/stores:
+    //   LDS row 64b + 16f + i   holds channel   64b + 32(f/2) + 8(i/4) + 4(f%2) + i%4
     unsigned woff[WJ];                                   // byte offset of this lane's weight chunk at k-slab 0
 #pragma unroll
     for (int j = 0; j < WJ; ++j) {
         const int row = (wave + NW * j) * 8 + rg;
+        const int f = (row >> 4) & 3, i = row & 15;
+        const int ch = (row & ~63) + ((f >> 1) << 5) + ((i >> 2) << 3) + ((f & 1) << 2) + (i & 3);
         const int lc = pc ^ ((row >> 1) & 7);
-        woff[j] = (co0 + row < p.cout) ? (unsigned)(row * p.K * 2 + lc * 16) : OOB;
+        woff[j] = (co0 + ch < p.cout) ? (unsigned)(ch * p.K * 2 + lc * 16) : OOB;
     }
     // activation rows: byte offset of (tap (0,0), channel 0) in each concat source, and a bit mask of the filter taps
     // whose input pixel exists (inside the image and left of valid_w) — kh*kw <= 32 on this path
@@ -189,7 +194,8 @@ __global__ void __launch_bounds__(WC * WP * 64, WC * WP / 4) conv_dma_kernel(con
         }
     }
 
-    // ---- epilogue (identical math to conv_igemm.hip)
+    // ---- epilogue (identical math to conv_igemm.hip; 8 consecutive channels per lane, see the weight-row permutation)
+    static_assert((BC / WC) % 64 == 0, "the channel permutation works on 64-channel blocks of a wave tile");
     f16* yo = reinterpret_cast<f16*>(p.y);
     const f16* rs = reinterpret_cast<const f16*>(p.res);
 #pragma unroll
@@ -199,23 +205,40 @@ __global__ void __launch_bounds__(WC * WP * 64, WC * WP / 4) conv_dma_kernel(con
         const int n = (p.out_scale || p.post_scale) ? pix / p.howo : 0;
         const int rpix = p.res_mod > 0 ? pix % p.res_mod : pix;
 #pragma unroll
-        for (int fa = 0; fa < FC; ++fa) {
-            const int co = co0 + wc * (BC / WC) + fa * 16 + g * 4;
+        for (int t = 0; t < FC / 2; ++t) {
+            const int co = co0 + wc * (BC / WC) + t * 32 + g * 8;
             if (co >= p.cout) continue;
-            f32x4 v = acc[fa][fb];
-            if (p.out_scale) v *= *reinterpret_cast<const f32x4*>(p.out_scale + (size_t)n * p.cout + co);
-            if (p.bias) v += *reinterpret_cast<const f32x4*>(p.bias + co);
+            float v[8];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) { v[q] = acc[2 * t][fb][q]; v[4 + q] = acc[2 * t + 1][fb][q]; }
+            if (p.out_scale) {
+                const f32x4 s0 = *reinterpret_cast<const f32x4*>(p.out_scale + (size_t)n * p.cout + co);
+                const f32x4 s1 = *reinterpret_cast<const f32x4*>(p.out_scale + (size_t)n * p.cout + co + 4);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) { v[q] *= s0[q]; v[4 + q] *= s1[q]; }
+            }
+            if (p.bias) {
+                const f32x4 b0 = *reinterpret_cast<const f32x4*>(p.bias + co);
+                const f32x4 b1 = *reinterpret_cast<const f32x4*>(p.bias + co + 4);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) { v[q] += b0[q]; v[4 + q] += b1[q]; }
+            }
             if (rs) {
-                const f16x4 r4 = *reinterpret_cast<const f16x4*>(rs + (size_t)rpix * p.cout + co);
-                v[0] += (float)r4[0]; v[1] += (float)r4[1]; v[2] += (float)r4[2]; v[3] += (float)r4[3];
+                const f16x8 r8 = bitcast<f16x8>(ldg16(rs + (size_t)rpix * p.cout + co));
+#pragma unroll
+                for (int q = 0; q < 8; ++q) v[q] += (float)r8[q];
             }
             if (p.act != MNET_ACT_NONE) {
-                v[0] = act_apply(v[0], p.act); v[1] = act_apply(v[1], p.act);
-                v[2] = act_apply(v[2], p.act); v[3] = act_apply(v[3], p.act);
+#pragma unroll
+                for (int q = 0; q < 8; ++q) v[q] = act_apply(v[q], p.act);
             }
-            if (p.post_scale) v *= *reinterpret_cast<const f32x4*>(p.post_scale + (size_t)n * p.cout + co);
-            const f16x4 o4 = {(f16)v[0], (f16)v[1], (f16)v[2], (f16)v[3]};
-            *reinterpret_cast<f16x4*>(yo + (size_t)pix * p.cout + co) = o4;
+            if (p.post_scale) {
+                const f32x4 s0 = *reinterpret_cast<const f32x4*>(p.post_scale + (size_t)n * p.cout + co);
+                const f32x4 s1 = *reinterpret_cast<const f32x4*>(p.post_scale + (size_t)n * p.cout + co + 4);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) { v[q] *= s0[q]; v[4 + q] *= s1[q]; }
+            }
+            stg16(yo + (size_t)pix * p.cout + co, Vec<f16>::pack(v));
         }
     }
 }
@@ -241,21 +264,37 @@ static int launch_dma_cfg(const ConvArgs& a, hipStream_t st) {
 // eligibility of the LDS-DMA path (see header comment); the caller falls back to the register-staged kernel
 bool conv_dma_eligible(const ConvArgs& a, int dtype) {
     if (dtype != MNET_F16 || a.in_scale) return false;
-    if (a.cin % 64 != 0 || a.c0 % 64 != 0 || a.cout < 64 || a.kh * a.kw > 32 || a.kh > 8 || a.kw > 8) return false;
+    if (a.cin % 64 != 0 || a.c0 % 64 != 0 || a.cout < 64 || a.cout % 8 != 0 || a.kh * a.kw > 32 || a.kh > 8 || a.kw > 8) return false;
     // 31-bit buffer offsets: a pixel tile may touch ceil(256/howo)+1 images
-    const long long imgs = 256 / a.howo + 2;   // largest pixel tile is 256
+    const long long imgs = 512 / a.howo + 2;   // largest pixel tile is 512
     const long long per_img = (long long)a.h * a.w * (a.c0 > a.c1 ? a.c0 : a.c1) * 2;
     if (per_img * imgs >= 0x7fffffffLL) return false;
     if ((long long)256 * a.K * 2 >= 0x40000000LL) return false;
+    if ((long long)a.cout * a.K * 2 >= 0x7fffffffLL) return false;
     return true;
 }
 
-int launch_conv_dma(const ConvArgs& a, hipStream_t st) {
-    static const int big = [] { const char* e = getenv("MNET_DMA_256"); return e ? atoi(e) : 1; }();   // tuning knob
-    if (a.cout >= 256) {
-        if (big && a.npix >= 256 * 256) return launch_dma_cfg<256, 256, 4, 4, 2>(a, st);
-        return launch_dma_cfg<256, 128, 4, 2, 3>(a, st);
+// tile configurations (BC x BP, waves, LDS stages); MNET_CONV_ALGO_DMA_CFG0 + id selects one explicitly
+static int launch_dma_id(int id, const ConvArgs& a, hipStream_t st) {
+    switch (id) {
+        case 0: return launch_dma_cfg<256, 256, 4, 4, 2>(a, st);
+        case 1: return launch_dma_cfg<256, 128, 4, 2, 3>(a, st);
+        case 2: return launch_dma_cfg<128, 256, 2, 4, 3>(a, st);
+        case 3: return launch_dma_cfg<64, 256, 1, 8, 3>(a, st);
+        case 4: return launch_dma_cfg<128, 512, 2, 8, 2>(a, st);
+        case 5: return launch_dma_cfg<64, 512, 1, 8, 2>(a, st);
+        case 6: return launch_dma_cfg<256, 256, 2, 4, 2>(a, st);     // 8 waves, 128x64 per wave (experimental)
+        default: return mnet_fail(MNET_E_ARG, "conv: unknown LDS-DMA tile configuration %d", id);
     }
-    if (a.cout >= 128) return launch_dma_cfg<128, 256, 2, 4, 3>(a, st);
-    return launch_dma_cfg<64, 256, 1, 8, 3>(a, st);
+}
+
+int conv_dma_pick(const ConvArgs& a) {
+    const bool big = a.npix >= 256 * 256;
+    if (a.cout >= 256) return big ? 0 : 1;
+    if (a.cout >= 128) return big ? 4 : 2;
+    return big ? 5 : 3;
+}
+
+int launch_conv_dma(const ConvArgs& a, hipStream_t st, int cfg) {
+    return launch_dma_id(cfg >= 0 ? cfg : conv_dma_pick(a), a, st);
 }

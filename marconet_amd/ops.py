@@ -52,10 +52,10 @@ class _Stats:
     def reset(self):
         self.conv_flops = 0.0
         self.conv_launches = 0
-        self.events = []       # (start, end, flops, dtype)
+        self.events = []       # (start, end, flops, dtype, kernel id from mnet_conv2d_plan)
 
     def conv_time_ms(self):
-        return sum(s.elapsed_time(e) for s, e, _, _ in self.events)
+        return sum(ev[0].elapsed_time(ev[1]) for ev in self.events)
 
 
 stats = _Stats()
@@ -114,7 +114,7 @@ def conv2d(x0, wgt, cout, kh=1, kw=1, stride=(1, 1), pad=(0, 0), x1=None, in_sca
             s.record()
             _lib.check(lib.mnet_conv2d_nhwc_ex(ctypes.byref(d), algo, _stream()), "mnet_conv2d_nhwc")
             e.record()
-            stats.events.append((s, e, fl, d.dtype))
+            stats.events.append((s, e, fl, d.dtype, lib.mnet_conv2d_plan(ctypes.byref(d), algo)))
             return out
     _lib.check(lib.mnet_conv2d_nhwc_ex(ctypes.byref(d), algo, _stream()), "mnet_conv2d_nhwc")
     return out

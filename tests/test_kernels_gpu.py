@@ -382,6 +382,31 @@ def test_conv_lds_dma_kernel(case):
     assert torch.equal(y_dma, y_reg), "LDS-DMA and register-staged kernels must agree bit for bit"
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("cfg", [0, 1, 2, 3, 4, 5])
+@pytest.mark.parametrize("shape", [(3, 40, 52, 64, 64, 200, 3), (700, 4, 4, 128, 0, 72, 3), (2, 9, 300, 192, 0, 320, 1)])
+def test_conv_lds_dma_every_tile_config(cfg, shape):
+    """every LDS-DMA tile configuration, pinned explicitly, is bit-identical to the register-staged kernel on shapes with
+    cout / pixel tails, two concat sources and ragged valid widths (ids in include/marconet_hip.h)"""
+    ops = _ops()
+    from marconet_amd._lib import ALGO_DMA_CFG0
+    dtype = torch.float16
+    n, h, w, c0, c1, cout, k = shape
+    x = _q(_rnd((n, c0 + c1, h, w), 71), dtype)
+    wt = _q(_rnd((cout, c0 + c1, k, k), 72, 1.0 / math.sqrt((c0 + c1) * k * k)), dtype)
+    bias = _rnd((cout,), 73, 0.3)
+    osc = _rnd((n, cout), 74).abs() + 0.5
+    res = _nhwc(_q(_rnd((n, cout, h, w), 76), dtype), dtype)
+    vw = torch.tensor([w - (i % 4) for i in range(n)], dtype=torch.int32, device=DEV)
+    x0 = _nhwc(x[:, :c0], dtype)
+    x1 = _nhwc(x[:, c0:], dtype) if c1 else None
+    kw = dict(x1=x1, valid_w=vw, out_scale=osc.to(DEV), bias=bias.to(DEV), residual=res, act=ops.ACT_LRELU_SQRT2)
+    y_cfg = ops.conv2d(x0, _pack_w(wt, dtype), cout, k, k, (1, 1), (k // 2, k // 2), algo=ALGO_DMA_CFG0 + cfg, **kw)
+    y_reg = ops.conv2d(x0, _pack_w(wt, dtype), cout, k, k, (1, 1), (k // 2, k // 2), algo=1, **kw)
+    torch.cuda.synchronize()
+    assert torch.equal(y_cfg, y_reg), "LDS-DMA tile configuration %d differs from the register-staged kernel" % cfg
+
+
 def test_conv_lds_dma_eligibility():
     ops = _ops()
     from marconet_amd._lib import MarconetHipError

@@ -56,13 +56,13 @@ def main():
     total = s0.elapsed_time(s1)
     lines = []
     tot_conv = 0.0
-    for r, (s, e, fl, d) in zip(recs, ops.stats.events):
+    for r, (s, e, fl, d, kid) in zip(recs, ops.stats.events):
         ms = s.elapsed_time(e)
         tot_conv += ms
-        lines.append("%-4s n=%-5d %4dx%-4d c=%3d+%-3d -> %4d k%d s%s out %4dx%-4d %s%s%s%s%s act%d  %8.3f ms %8.1f TF/s %5.1f%%"
+        lines.append("%-4s n=%-5d %4dx%-4d c=%3d+%-3d -> %4d k%d s%s out %4dx%-4d %s%s%s%s%s act%d k%-2d %8.3f ms %8.1f TF/s %5.1f%%"
                      % ("f16" if r["dt"] else "f32", r["n"], r["h"], r["w"], r["c0"], r["c1"], r["cout"], r["k"], r["s"], r["ho"], r["wo"],
                         "P" if r["pro"] else "-", "S" if r["sw"] else "-", "V" if r["vw"] else "-", "D" if r["osc"] else "-",
-                        "R" if r["res"] else "-", r["act"], ms, fl / ms / 1e9, 100 * ms / total))
+                        "R" if r["res"] else "-", r["act"], kid, ms, fl / ms / 1e9, 100 * ms / total))
     lines.append("step total %.2f ms, conv launches %.2f ms (%d), other %.2f ms" % (total, tot_conv, len(recs), total - tot_conv))
     os.makedirs(os.path.dirname(a.out), exist_ok=True)
     open(a.out, "w").write("\n".join(lines) + "\n")
