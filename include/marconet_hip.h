@@ -96,9 +96,14 @@ typedef struct {
 int mnet_conv2d_nhwc(const mnet_conv_desc* d, void* stream);
 
 /* same with an explicit kernel choice (A/B measurements, tests): AUTO picks the LDS-DMA kernel when the launch is
- * eligible (f16, (c0+c1) % 64 == 0, c0 % 64 == 0, cout >= 64, cout % 8 == 0, no in_scale) and the register-staged
- * one otherwise; MNET_CONV_ALGO_DMA_CFG0 + id pins one LDS-DMA tile configuration (cout x pixel tile, waves, stages):
- *   id 0: 256x256 16w 2st   1: 256x128 8w 3st   2: 128x256 8w 3st   3: 64x256 8w 3st   4: 128x512 16w 2st   5: 64x512 8w 2st */
+ * eligible (f16, (c0+c1) % 64 == 0, c0 % 64 == 0, cout >= 64, cout % 8 == 0, no in_scale, act <= LRELU_SQRT2) and the
+ * register-staged one otherwise; MNET_CONV_ALGO_DMA_CFG0 + id pins one LDS-DMA tile configuration
+ * (cout x pixel tile, waves, LDS stages):
+ *   id 0: 256x256 16w 2st   1: 256x128 8w 3st   2: 128x256 8w 3st   3: 64x256 8w 3st   4: 128x512 16w 2st
+ *      5: 64x512 8w 2st     6: 256x256 8w 2st (128x64 per wave)      — all on v_mfma_f32_16x16x32_f16 with the k association
+ *      of the register-staged kernel: every f16 launch yields the same bits whichever kernel / tile its size selects
+ *   id 7/8/9: ids 0/4/5 on v_mfma_f32_32x32x16_f16 (experimental; fp32 partial sums associate differently)
+ *   id 11-15: diagnostic builds used by tools/wg_timeline.py and tools/conv_bench.py; they produce WRONG results */
 enum { MNET_CONV_ALGO_AUTO = 0, MNET_CONV_ALGO_REG_STAGED = 1, MNET_CONV_ALGO_LDS_DMA = 2, MNET_CONV_ALGO_DMA_CFG0 = 16 };
 int mnet_conv2d_nhwc_ex(const mnet_conv_desc* d, int32_t algo, void* stream);
 

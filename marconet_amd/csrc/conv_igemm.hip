@@ -53,11 +53,11 @@ __device__ __forceinline__ u32x4 in_transform(u32x4 raw, const float* sc, const 
         f32x4 b4 = {0.f, 0.f, 0.f, 0.f};
         if (sh) b4 = *reinterpret_cast<const f32x4*>(sh + j);
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            float t = v[j + q] * s4[q] + b4[q];
-            if (swish) t = t * (1.f / (1.f + expf(-t)));
-            v[j + q] = t;
-        }
+        for (int q = 0; q < 4; ++q) v[j + q] = v[j + q] * s4[q] + b4[q];
+    }
+    if (swish) {          // one wave-uniform branch, not one per element
+#pragma unroll
+        for (int j = 0; j < N; ++j) v[j] = v[j] * (1.f / (1.f + expf(-v[j])));
     }
     return Vec<T>::pack(v);
 }
@@ -196,37 +196,85 @@ __global__ void __launch_bounds__(256, 2) conv_igemm_kernel(const ConvArgs p) {
         __syncthreads();
     }
 
-    // ---- epilogue: lane owns channels co..co+3 of one pixel per fragment
+    // ---- epilogue: lane owns channels co..co+3 (fragment fa) of one pixel (fragment fb).  Whole-register-set passes, each
+    // behind ONE wave-uniform branch (a per-element `switch (act)` costs a scalar branch chain per value).
     T* yo = reinterpret_cast<T*>(p.y);
-    const T* rs = reinterpret_cast<const T*>(p.res);
+    int epix[FP], eco[FC];
 #pragma unroll
-    for (int fb = 0; fb < FP; ++fb) {
-        const int pix = pix0 + wp * (BP / WP) + fb * 16 + l16;
-        if (pix >= p.npix) continue;
-        const int n = (p.out_scale || p.post_scale) ? pix / p.howo : 0;
-        const int rpix = p.res_mod > 0 ? pix % p.res_mod : pix;
+    for (int fb = 0; fb < FP; ++fb) epix[fb] = pix0 + wp * (BP / WP) + fb * 16 + l16;
+#pragma unroll
+    for (int fa = 0; fa < FC; ++fa) eco[fa] = co0 + wc * (BC / WC) + fa * 16 + g * 4;
+    const int last_pix = p.npix - 1;
+    if (p.out_scale) {
+#pragma unroll
+        for (int fb = 0; fb < FP; ++fb) {
+            const float* sp = p.out_scale + (size_t)(min(epix[fb], last_pix) / p.howo) * p.cout;
+#pragma unroll
+            for (int fa = 0; fa < FC; ++fa)
+                if (eco[fa] < p.cout) acc[fa][fb] *= *reinterpret_cast<const f32x4*>(sp + eco[fa]);
+        }
+    }
+    if (p.bias) {
 #pragma unroll
         for (int fa = 0; fa < FC; ++fa) {
-            const int co = co0 + wc * (BC / WC) + fa * 16 + g * 4;
-            if (co >= p.cout) continue;
-            f32x4 v = acc[fa][fb];
-            if (p.out_scale) v *= *reinterpret_cast<const f32x4*>(p.out_scale + (size_t)n * p.cout + co);
-            if (p.bias) v += *reinterpret_cast<const f32x4*>(p.bias + co);
-            if (rs) {
-                const T* rp = rs + (size_t)rpix * p.cout + co;
+            if (eco[fa] >= p.cout) continue;
+            const f32x4 b4 = *reinterpret_cast<const f32x4*>(p.bias + eco[fa]);
+#pragma unroll
+            for (int fb = 0; fb < FP; ++fb) acc[fa][fb] += b4;
+        }
+    }
+    if (p.res) {
+        const T* rs = reinterpret_cast<const T*>(p.res);
+#pragma unroll
+        for (int fb = 0; fb < FP; ++fb) {
+            if (epix[fb] >= p.npix) continue;
+            const int rpix = p.res_mod > 0 ? epix[fb] % p.res_mod : epix[fb];
+#pragma unroll
+            for (int fa = 0; fa < FC; ++fa) {
+                if (eco[fa] >= p.cout) continue;
+                const T* rp = rs + (size_t)rpix * p.cout + eco[fa];
                 if constexpr (sizeof(T) == 4) {
-                    v += *reinterpret_cast<const f32x4*>(rp);
+                    acc[fa][fb] += *reinterpret_cast<const f32x4*>(rp);
                 } else {
                     const f16x4 r4 = *reinterpret_cast<const f16x4*>(rp);
-                    v[0] += (float)r4[0]; v[1] += (float)r4[1]; v[2] += (float)r4[2]; v[3] += (float)r4[3];
+                    acc[fa][fb] += f32x4{(float)r4[0], (float)r4[1], (float)r4[2], (float)r4[3]};
                 }
             }
-            if (p.act != MNET_ACT_NONE) {
-                v[0] = act_apply(v[0], p.act); v[1] = act_apply(v[1], p.act);
-                v[2] = act_apply(v[2], p.act); v[3] = act_apply(v[3], p.act);
-            }
-            if (p.post_scale) v *= *reinterpret_cast<const f32x4*>(p.post_scale + (size_t)n * p.cout + co);
-            T* yp = yo + (size_t)pix * p.cout + co;
+        }
+    }
+    {
+        float ev[FC * FP * 4];
+#pragma unroll
+        for (int fa = 0; fa < FC; ++fa)
+#pragma unroll
+            for (int fb = 0; fb < FP; ++fb)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) ev[(fa * FP + fb) * 4 + q] = acc[fa][fb][q];
+        act_apply_vec<FC * FP * 4>(ev, p.act);
+#pragma unroll
+        for (int fa = 0; fa < FC; ++fa)
+#pragma unroll
+            for (int fb = 0; fb < FP; ++fb)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) acc[fa][fb][q] = ev[(fa * FP + fb) * 4 + q];
+    }
+    if (p.post_scale) {
+#pragma unroll
+        for (int fb = 0; fb < FP; ++fb) {
+            const float* sp = p.post_scale + (size_t)(min(epix[fb], last_pix) / p.howo) * p.cout;
+#pragma unroll
+            for (int fa = 0; fa < FC; ++fa)
+                if (eco[fa] < p.cout) acc[fa][fb] *= *reinterpret_cast<const f32x4*>(sp + eco[fa]);
+        }
+    }
+#pragma unroll
+    for (int fb = 0; fb < FP; ++fb) {
+        if (epix[fb] >= p.npix) continue;
+#pragma unroll
+        for (int fa = 0; fa < FC; ++fa) {
+            if (eco[fa] >= p.cout) continue;
+            T* yp = yo + (size_t)epix[fb] * p.cout + eco[fa];
+            const f32x4 v = acc[fa][fb];
             if constexpr (sizeof(T) == 4) {
                 *reinterpret_cast<f32x4*>(yp) = v;
             } else {

@@ -23,7 +23,22 @@ __device__ __forceinline__ int swz_dma(int row, int chunk) { return row * 128 + 
 
 #define VMCNT(n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
 
-template <int BC, int BP, int WC, int WP, int STAGES>
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+// store 8 consecutive output channels co..co+7 of pixel `pix` (DBG: diagnostic variants, see launch_dma_id)
+template <int DBG>
+__device__ __forceinline__ void store8(const ConvArgs& p, const float* v, int pix, int co) {
+    if constexpr (DBG == 5) {           // DIAGNOSTIC: no stores (values kept live)
+        asm volatile("" :: "v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]), "v"(v[4]), "v"(v[5]), "v"(v[6]), "v"(v[7]));
+        return;
+    }
+    if constexpr (DBG == 4) pix &= 255;  // DIAGNOSTIC: every tile stores over tile 0 (L2-resident writes)
+    stg16(reinterpret_cast<f16*>(p.y) + (size_t)pix * p.cout + co, Vec<f16>::pack(v));
+}
+
+// MF = 16: v_mfma_f32_16x16x32_f16 — production (same k association as conv_igemm.hip → bit-identical to it);
+// MF = 32: v_mfma_f32_32x32x16_f16 — experimental (half the matrix instructions per slab, measured ~10 % slower in this loop)
+template <int BC, int BP, int WC, int WP, int STAGES, int MF = 16, int DBG = 0>
 __global__ void __launch_bounds__(WC * WP * 64, WC * WP / 4) conv_dma_kernel(const ConvArgs p) {
     constexpr int NW = WC * WP;                          // waves per workgroup (8 or 16)
     constexpr int FC = BC / WC / 16, FP = BP / WP / 16;
@@ -40,6 +55,8 @@ __global__ void __launch_bounds__(WC * WP * 64, WC * WP / 4) conv_dma_kernel(con
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wc = wave / WP, wp = wave % WP;
     const int l16 = lane & 15, g = lane >> 4;
+    long long stamp[4] = {0, 0, 0, 0};                   // DBG == 3 only: wall-clock (100 MHz) at entry / loop start / loop end / exit
+    if constexpr (DBG >= 3) stamp[0] = wall_clock64();
 
     const int nwg = gridDim.x, bid = blockIdx.x;
     const int q8 = nwg >> 3, r8 = nwg & 7, xcd = bid & 7;
@@ -66,13 +83,19 @@ __global__ void __launch_bounds__(WC * WP * 64, WC * WP / 4) conv_dma_kernel(con
     const int rg = lane >> 3, pc = lane & 7;
     // Weight rows are permuted on their way into LDS (free: the DMA source address is per lane) so that the two MFMA
     // fragments 2t, 2t+1 of a lane together hold 8 CONSECUTIVE output channels → 16-byte epilogue loads/stores:
-    //   LDS row 64b + 16f + i   holds channel   64b + 32(f/2) + 8(i/4) + 4(f%2) + i%4
+    //   LDS row 64b + 16f + i   holds channel   64b + 32(f/2) + 8(i/4) + 4(f%2) + i%4        (MF = 16)
     unsigned woff[WJ];                                   // byte offset of this lane's weight chunk at k-slab 0
 #pragma unroll
     for (int j = 0; j < WJ; ++j) {
         const int row = (wave + NW * j) * 8 + rg;
-        const int f = (row >> 4) & 3, i = row & 15;
-        const int ch = (row & ~63) + ((f >> 1) << 5) + ((i >> 2) << 3) + ((f & 1) << 2) + (i & 3);
+        int ch;
+        if constexpr (MF == 16) {
+            const int f = (row >> 4) & 3, i = row & 15;
+            ch = (row & ~63) + ((f >> 1) << 5) + ((i >> 2) << 3) + ((f & 1) << 2) + (i & 3);
+        } else {   // 32x32 tile: D row i = 8q + 4h + e of lane-half h  →  channel 16h + 4q + e (16 consecutive per lane)
+            const int i = row & 31;
+            ch = (row & ~31) + (((i >> 2) & 1) << 4) + ((i >> 3) << 2) + (i & 3);
+        }
         const int lc = pc ^ ((row >> 1) & 7);
         woff[j] = (co0 + ch < p.cout) ? (unsigned)(ch * p.K * 2 + lc * 16) : OOB;
     }
@@ -111,6 +134,7 @@ __global__ void __launch_bounds__(WC * WP * 64, WC * WP / 4) conv_dma_kernel(con
         unsigned char* sw_ = smem + stage * STAGE;
         unsigned char* sx_ = sw_ + BC * 128;
         const unsigned kb = (unsigned)cur_k * 2u;
+        if constexpr (DBG == 2) { if (cur_k > 0) { cur_k += 64; return; } }   // diagnostic: no DMA after the first slab (results wrong)
 #pragma unroll
         for (int j = 0; j < WJ; ++j) {
             const unsigned vo = woff[j] == OOB ? OOB : woff[j] + kb;
@@ -128,7 +152,8 @@ __global__ void __launch_bounds__(WC * WP * 64, WC * WP / 4) conv_dma_kernel(con
             const unsigned uni = (unsigned)(cur_tpx * p.c0 * 2 + cur_c * 2);
 #pragma unroll
             for (int j = 0; j < XJ; ++j) {
-                const unsigned vo = (xmask[j] & tapbit) ? xb0[j] + uni : OOB;
+                unsigned vo = (xmask[j] & tapbit) ? xb0[j] + uni : OOB;
+                if constexpr (DBG == 1) vo = (xb0[j] & 0x3ffffu) + (unsigned)(cur_c * 2);   // diagnostic: activations from a 256 KiB window (L2-resident; results wrong)
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(rX0, (lds_void*)(sx_ + (wave + NW * j) * 1024), 16, vo, 0, 0, 0);
             }
         }
@@ -140,15 +165,25 @@ __global__ void __launch_bounds__(WC * WP * 64, WC * WP / 4) conv_dma_kernel(con
     };
 
     f32x4 acc[FC][FP];
+    f32x16 acc32[MF == 32 ? FC / 2 : 1][MF == 32 ? FP / 2 : 1];
+    if constexpr (MF == 16) {
 #pragma unroll
-    for (int a = 0; a < FC; ++a)
+        for (int a = 0; a < FC; ++a)
 #pragma unroll
-        for (int b = 0; b < FP; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+            for (int b = 0; b < FP; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+    } else {
+#pragma unroll
+        for (int a = 0; a < FC / 2; ++a)
+#pragma unroll
+            for (int b = 0; b < FP / 2; ++b)
+#pragma unroll
+                for (int q = 0; q < 16; ++q) acc32[a][b][q] = 0.f;
+    }
 
     auto compute_half = [&](int stage, int ks) __attribute__((always_inline)) {
         const unsigned char* sw_ = smem + stage * STAGE;
         const unsigned char* sx_ = sw_ + BC * 128;
-        {
+        if constexpr (MF == 16) {
             const int chunk = ks * 4 + g;
             u32x4 a[FC], b[FP];
 #pragma unroll
@@ -160,10 +195,27 @@ __global__ void __launch_bounds__(WC * WP * 64, WC * WP / 4) conv_dma_kernel(con
 #pragma unroll
                 for (int fb = 0; fb < FP; ++fb)
                     acc[fa][fb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bitcast<f16x8>(a[fa]), bitcast<f16x8>(b[fb]), acc[fa][fb], 0, 0, 0);
+        } else {
+            const int l32 = lane & 31, h = lane >> 5;
+#pragma unroll
+            for (int k2 = 0; k2 < 2; ++k2) {                 // two 16-deep k-steps per half slab
+                const int chunk = ks * 4 + k2 * 2 + h;
+                u32x4 a[FC / 2], b[FP / 2];
+#pragma unroll
+                for (int f = 0; f < FC / 2; ++f) a[f] = *reinterpret_cast<const u32x4*>(sw_ + swz_dma(wc * (BC / WC) + f * 32 + l32, chunk));
+#pragma unroll
+                for (int f = 0; f < FP / 2; ++f) b[f] = *reinterpret_cast<const u32x4*>(sx_ + swz_dma(wp * (BP / WP) + f * 32 + l32, chunk));
+#pragma unroll
+                for (int fa = 0; fa < FC / 2; ++fa)
+#pragma unroll
+                    for (int fb = 0; fb < FP / 2; ++fb)
+                        acc32[fa][fb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bitcast<f16x8>(a[fa]), bitcast<f16x8>(b[fb]), acc32[fa][fb], 0, 0, 0);
+            }
         }
     };
 
     const int nk = p.ktiles;
+    if constexpr (DBG >= 3) stamp[1] = wall_clock64();
     if constexpr (STAGES == 3) {
         // ---- 3-stage ring: slab t+1 stays in flight across the barrier of slab t (counted vmcnt, never 0 in the loop)
         issue_slab(0);
@@ -194,59 +246,109 @@ __global__ void __launch_bounds__(WC * WP * 64, WC * WP / 4) conv_dma_kernel(con
         }
     }
 
-    // ---- epilogue (identical math to conv_igemm.hip; 8 consecutive channels per lane, see the weight-row permutation)
-    static_assert((BC / WC) % 64 == 0, "the channel permutation works on 64-channel blocks of a wave tile");
-    f16* yo = reinterpret_cast<f16*>(p.y);
-    const f16* rs = reinterpret_cast<const f16*>(p.res);
+    if constexpr (DBG >= 3) stamp[2] = wall_clock64();
+    // ---- epilogue (identical math to conv_igemm.hip).  Thanks to the weight-row permutation every lane owns NG groups of
+    // 8 consecutive output channels for each of its NPX pixels.  The epilogue runs as whole-register-set passes, each
+    // behind ONE wave-uniform branch (out_scale / bias / residual / activation / post_scale), then 16-byte stores.
+    static_assert((BC / WC) % 64 == 0 && (BP / WP) % 32 == 0, "the channel permutation works on 64-channel blocks of a wave tile");
+    constexpr int NPX = MF == 16 ? FP : FP / 2;          // pixels per lane
+    constexpr int NG = MF == 16 ? FC / 2 : FC;           // 8-channel groups per pixel per lane
+    float ev[NPX][NG][8];
+    int epix[NPX], eco[NG];
 #pragma unroll
-    for (int fb = 0; fb < FP; ++fb) {
-        const int pix = pix0 + wp * (BP / WP) + fb * 16 + l16;
-        if (pix >= p.npix) continue;
-        const int n = (p.out_scale || p.post_scale) ? pix / p.howo : 0;
-        const int rpix = p.res_mod > 0 ? pix % p.res_mod : pix;
+    for (int gi = 0; gi < NG; ++gi)
+        eco[gi] = MF == 16 ? co0 + wc * (BC / WC) + gi * 32 + g * 8
+                           : co0 + wc * (BC / WC) + (gi >> 1) * 32 + (lane >> 5) * 16 + (gi & 1) * 8;
 #pragma unroll
-        for (int t = 0; t < FC / 2; ++t) {
-            const int co = co0 + wc * (BC / WC) + t * 32 + g * 8;
-            if (co >= p.cout) continue;
-            float v[8];
+    for (int px = 0; px < NPX; ++px) {
+        epix[px] = MF == 16 ? pix0 + wp * (BP / WP) + px * 16 + l16 : pix0 + wp * (BP / WP) + px * 32 + (lane & 31);
 #pragma unroll
-            for (int q = 0; q < 4; ++q) { v[q] = acc[2 * t][fb][q]; v[4 + q] = acc[2 * t + 1][fb][q]; }
-            if (p.out_scale) {
-                const f32x4 s0 = *reinterpret_cast<const f32x4*>(p.out_scale + (size_t)n * p.cout + co);
-                const f32x4 s1 = *reinterpret_cast<const f32x4*>(p.out_scale + (size_t)n * p.cout + co + 4);
+        for (int gi = 0; gi < NG; ++gi)
 #pragma unroll
-                for (int q = 0; q < 4; ++q) { v[q] *= s0[q]; v[4 + q] *= s1[q]; }
+            for (int q = 0; q < 8; ++q) {
+                if constexpr (MF == 16) ev[px][gi][q] = acc[2 * gi + (q >> 2)][px][q & 3];
+                else ev[px][gi][q] = acc32[gi >> 1][px][(gi & 1) * 8 + q];
             }
-            if (p.bias) {
-                const f32x4 b0 = *reinterpret_cast<const f32x4*>(p.bias + co);
-                const f32x4 b1 = *reinterpret_cast<const f32x4*>(p.bias + co + 4);
+    }
+    const int last_pix = p.npix - 1;
+    if (p.out_scale) {
 #pragma unroll
-                for (int q = 0; q < 4; ++q) { v[q] += b0[q]; v[4 + q] += b1[q]; }
-            }
-            if (rs) {
-                const f16x8 r8 = bitcast<f16x8>(ldg16(rs + (size_t)rpix * p.cout + co));
+        for (int px = 0; px < NPX; ++px) {
+            const float* sp = p.out_scale + (size_t)(min(epix[px], last_pix) / p.howo) * p.cout;
 #pragma unroll
-                for (int q = 0; q < 8; ++q) v[q] += (float)r8[q];
-            }
-            if (p.act != MNET_ACT_NONE) {
+            for (int gi = 0; gi < NG; ++gi) {
+                if (eco[gi] >= p.cout) continue;
+                const f32x4 s0 = *reinterpret_cast<const f32x4*>(sp + eco[gi]), s1 = *reinterpret_cast<const f32x4*>(sp + eco[gi] + 4);
 #pragma unroll
-                for (int q = 0; q < 8; ++q) v[q] = act_apply(v[q], p.act);
+                for (int q = 0; q < 4; ++q) { ev[px][gi][q] *= s0[q]; ev[px][gi][4 + q] *= s1[q]; }
             }
-            if (p.post_scale) {
-                const f32x4 s0 = *reinterpret_cast<const f32x4*>(p.post_scale + (size_t)n * p.cout + co);
-                const f32x4 s1 = *reinterpret_cast<const f32x4*>(p.post_scale + (size_t)n * p.cout + co + 4);
+        }
+    }
+    if (p.bias) {
 #pragma unroll
-                for (int q = 0; q < 4; ++q) { v[q] *= s0[q]; v[4 + q] *= s1[q]; }
+        for (int gi = 0; gi < NG; ++gi) {
+            if (eco[gi] >= p.cout) continue;
+            const f32x4 b0 = *reinterpret_cast<const f32x4*>(p.bias + eco[gi]), b1 = *reinterpret_cast<const f32x4*>(p.bias + eco[gi] + 4);
+#pragma unroll
+            for (int px = 0; px < NPX; ++px)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) { ev[px][gi][q] += b0[q]; ev[px][gi][4 + q] += b1[q]; }
+        }
+    }
+    if (p.res) {
+        const f16* rs = reinterpret_cast<const f16*>(p.res);
+#pragma unroll
+        for (int px = 0; px < NPX; ++px) {
+            if (epix[px] >= p.npix) continue;
+            const int rpix = p.res_mod > 0 ? epix[px] % p.res_mod : epix[px];
+#pragma unroll
+            for (int gi = 0; gi < NG; ++gi) {
+                if (eco[gi] >= p.cout) continue;
+                const f16x8 r8 = bitcast<f16x8>(ldg16(rs + (size_t)rpix * p.cout + eco[gi]));
+#pragma unroll
+                for (int q = 0; q < 8; ++q) ev[px][gi][q] += (float)r8[q];
             }
-            stg16(yo + (size_t)pix * p.cout + co, Vec<f16>::pack(v));
+        }
+    }
+    act_apply_vec<NPX * NG * 8, true>(&ev[0][0][0], p.act);     // this path only takes the cheap (branch-free) activations
+    if (p.post_scale) {
+#pragma unroll
+        for (int px = 0; px < NPX; ++px) {
+            const float* sp = p.post_scale + (size_t)(min(epix[px], last_pix) / p.howo) * p.cout;
+#pragma unroll
+            for (int gi = 0; gi < NG; ++gi) {
+                if (eco[gi] >= p.cout) continue;
+                const f32x4 s0 = *reinterpret_cast<const f32x4*>(sp + eco[gi]), s1 = *reinterpret_cast<const f32x4*>(sp + eco[gi] + 4);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) { ev[px][gi][q] *= s0[q]; ev[px][gi][4 + q] *= s1[q]; }
+            }
+        }
+    }
+#pragma unroll
+    for (int px = 0; px < NPX; ++px) {
+        if (epix[px] >= p.npix) continue;
+#pragma unroll
+        for (int gi = 0; gi < NG; ++gi)
+            if (eco[gi] < p.cout) store8<DBG>(p, ev[px][gi], epix[px], eco[gi]);
+    }
+    if constexpr (DBG >= 3) {       // DIAGNOSTIC: overwrite the head of this workgroup's output tile with its time stamps
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        stamp[3] = wall_clock64();
+        if (tid == 0) {
+            long long* o = DBG == 3 ? reinterpret_cast<long long*>(reinterpret_cast<f16*>(p.y) + (size_t)pix0 * p.cout + co0)
+                                    : reinterpret_cast<long long*>(reinterpret_cast<f16*>(p.y) + (size_t)(256 + 32 * (size_t)wg) * p.cout);
+            o[0] = 0x7157a3b5ll; o[1] = stamp[0]; o[2] = stamp[1]; o[3] = stamp[2]; o[4] = stamp[3];
+            o[5] = __builtin_amdgcn_s_getreg((31 << 11) | 4);    // HW_ID
+            o[6] = __builtin_amdgcn_s_getreg((31 << 11) | 20);   // XCC_ID
+            o[7] = bid;
         }
     }
 }
 
-template <int BC, int BP, int WC, int WP, int STAGES>
+template <int BC, int BP, int WC, int WP, int STAGES, int MF = 16, int DBG = 0>
 static int launch_dma_cfg(const ConvArgs& a, hipStream_t st) {
     constexpr int LDS = STAGES * (BC + BP) * 128;
-    auto kern = conv_dma_kernel<BC, BP, WC, WP, STAGES>;
+    auto kern = conv_dma_kernel<BC, BP, WC, WP, STAGES, MF, DBG>;
     static thread_local bool attr_set = false;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
@@ -263,7 +365,7 @@ static int launch_dma_cfg(const ConvArgs& a, hipStream_t st) {
 
 // eligibility of the LDS-DMA path (see header comment); the caller falls back to the register-staged kernel
 bool conv_dma_eligible(const ConvArgs& a, int dtype) {
-    if (dtype != MNET_F16 || a.in_scale) return false;
+    if (dtype != MNET_F16 || a.in_scale || a.act > MNET_ACT_LRELU_SQRT2) return false;
     if (a.cin % 64 != 0 || a.c0 % 64 != 0 || a.cout < 64 || a.cout % 8 != 0 || a.kh * a.kw > 32 || a.kh > 8 || a.kw > 8) return false;
     // 31-bit buffer offsets: a pixel tile may touch ceil(256/howo)+1 images
     const long long imgs = 512 / a.howo + 2;   // largest pixel tile is 512
@@ -274,7 +376,11 @@ bool conv_dma_eligible(const ConvArgs& a, int dtype) {
     return true;
 }
 
-// tile configurations (BC x BP, waves, LDS stages); MNET_CONV_ALGO_DMA_CFG0 + id selects one explicitly
+// tile configurations (BC x BP, waves, LDS stages, MFMA shape); MNET_CONV_ALGO_DMA_CFG0 + id selects one explicitly.
+// Production ids 0-6 all use v_mfma_f32_16x16x32_f16 with the register-staged kernel's k association, so every f16 conv
+// launch gives the same bits whatever kernel / tile configuration its size selects (batch-size-invariant results).
+// ids 7-9: v_mfma_f32_32x32x16_f16 forms (measured ~10 % slower here; fp32 sums associate differently).
+// ids 11-15: DIAGNOSTIC builds that produce wrong results on purpose (tools/wg_timeline.py, tools/conv_bench.py).
 static int launch_dma_id(int id, const ConvArgs& a, hipStream_t st) {
     switch (id) {
         case 0: return launch_dma_cfg<256, 256, 4, 4, 2>(a, st);
@@ -283,7 +389,15 @@ static int launch_dma_id(int id, const ConvArgs& a, hipStream_t st) {
         case 3: return launch_dma_cfg<64, 256, 1, 8, 3>(a, st);
         case 4: return launch_dma_cfg<128, 512, 2, 8, 2>(a, st);
         case 5: return launch_dma_cfg<64, 512, 1, 8, 2>(a, st);
-        case 6: return launch_dma_cfg<256, 256, 2, 4, 2>(a, st);     // 8 waves, 128x64 per wave (experimental)
+        case 6: return launch_dma_cfg<256, 256, 2, 4, 2>(a, st);          // 8 waves, 128x64 per wave
+        case 7: return launch_dma_cfg<256, 256, 4, 4, 2, 32>(a, st);
+        case 8: return launch_dma_cfg<128, 512, 2, 8, 2, 32>(a, st);
+        case 9: return launch_dma_cfg<64, 512, 1, 8, 2, 32>(a, st);
+        case 11: return launch_dma_cfg<256, 256, 4, 4, 2, 16, 4>(a, st);  // DIAGNOSTIC: all tiles store over tile 0; stamps after tile 0
+        case 12: return launch_dma_cfg<256, 256, 4, 4, 2, 16, 5>(a, st);  // DIAGNOSTIC: no output stores; stamps after tile 0
+        case 13: return launch_dma_cfg<256, 256, 4, 4, 2, 16, 3>(a, st);  // DIAGNOSTIC: per-workgroup time stamps written over the output
+        case 14: return launch_dma_cfg<256, 256, 4, 4, 2, 16, 1>(a, st);  // DIAGNOSTIC: activations read from a 256 KiB window
+        case 15: return launch_dma_cfg<256, 256, 4, 4, 2, 16, 2>(a, st);  // DIAGNOSTIC: no DMA after the first k-slab
         default: return mnet_fail(MNET_E_ARG, "conv: unknown LDS-DMA tile configuration %d", id);
     }
 }
