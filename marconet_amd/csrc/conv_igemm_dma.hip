@@ -38,7 +38,7 @@ __device__ __forceinline__ void store8(const ConvArgs& p, const float* v, int pi
 
 // MF = 16: v_mfma_f32_16x16x32_f16 — production (same k association as conv_igemm.hip → bit-identical to it);
 // MF = 32: v_mfma_f32_32x32x16_f16 — experimental (half the matrix instructions per slab, measured ~10 % slower in this loop)
-template <int BC, int BP, int WC, int WP, int STAGES, int MF = 16, int DBG = 0>
+template <int BC, int BP, int WC, int WP, int STAGES, int MF = 16, int DBG = 0, int PIPE = 0>
 __global__ void __launch_bounds__(WC * WP * 64, WC * WP / 4) conv_dma_kernel(const ConvArgs p) {
     constexpr int NW = WC * WP;                          // waves per workgroup (8 or 16)
     constexpr int FC = BC / WC / 16, FP = BP / WP / 16;
@@ -180,43 +180,101 @@ __global__ void __launch_bounds__(WC * WP * 64, WC * WP / 4) conv_dma_kernel(con
                 for (int q = 0; q < 16; ++q) acc32[a][b][q] = 0.f;
     }
 
-    auto compute_half = [&](int stage, int ks) __attribute__((always_inline)) {
+    // fragments of one half slab (32 k): FC weight + FP activation 16-byte chunks per lane (MF = 32: [k-step][fragment])
+    auto read_half = [&](int stage, int ks, u32x4* a, u32x4* b) __attribute__((always_inline)) {
         const unsigned char* sw_ = smem + stage * STAGE;
         const unsigned char* sx_ = sw_ + BC * 128;
         if constexpr (MF == 16) {
             const int chunk = ks * 4 + g;
-            u32x4 a[FC], b[FP];
 #pragma unroll
             for (int f = 0; f < FC; ++f) a[f] = *reinterpret_cast<const u32x4*>(sw_ + swz_dma(wc * (BC / WC) + f * 16 + l16, chunk));
 #pragma unroll
             for (int f = 0; f < FP; ++f) b[f] = *reinterpret_cast<const u32x4*>(sx_ + swz_dma(wp * (BP / WP) + f * 16 + l16, chunk));
+        } else {
+            const int l32 = lane & 31, h = lane >> 5;
+#pragma unroll
+            for (int k2 = 0; k2 < 2; ++k2) {                 // two 16-deep k-steps per half slab
+                const int chunk = ks * 4 + k2 * 2 + h;
+#pragma unroll
+                for (int f = 0; f < FC / 2; ++f) a[k2 * (FC / 2) + f] = *reinterpret_cast<const u32x4*>(sw_ + swz_dma(wc * (BC / WC) + f * 32 + l32, chunk));
+#pragma unroll
+                for (int f = 0; f < FP / 2; ++f) b[k2 * (FP / 2) + f] = *reinterpret_cast<const u32x4*>(sx_ + swz_dma(wp * (BP / WP) + f * 32 + l32, chunk));
+            }
+        }
+    };
+    auto mfma_half = [&](const u32x4* a, const u32x4* b) __attribute__((always_inline)) {
+        if constexpr (MF == 16) {
 #pragma unroll
             for (int fa = 0; fa < FC; ++fa)
 #pragma unroll
                 for (int fb = 0; fb < FP; ++fb)
                     acc[fa][fb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bitcast<f16x8>(a[fa]), bitcast<f16x8>(b[fb]), acc[fa][fb], 0, 0, 0);
         } else {
-            const int l32 = lane & 31, h = lane >> 5;
 #pragma unroll
-            for (int k2 = 0; k2 < 2; ++k2) {                 // two 16-deep k-steps per half slab
-                const int chunk = ks * 4 + k2 * 2 + h;
-                u32x4 a[FC / 2], b[FP / 2];
-#pragma unroll
-                for (int f = 0; f < FC / 2; ++f) a[f] = *reinterpret_cast<const u32x4*>(sw_ + swz_dma(wc * (BC / WC) + f * 32 + l32, chunk));
-#pragma unroll
-                for (int f = 0; f < FP / 2; ++f) b[f] = *reinterpret_cast<const u32x4*>(sx_ + swz_dma(wp * (BP / WP) + f * 32 + l32, chunk));
+            for (int k2 = 0; k2 < 2; ++k2)
 #pragma unroll
                 for (int fa = 0; fa < FC / 2; ++fa)
 #pragma unroll
                     for (int fb = 0; fb < FP / 2; ++fb)
-                        acc32[fa][fb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bitcast<f16x8>(a[fa]), bitcast<f16x8>(b[fb]), acc32[fa][fb], 0, 0, 0);
-            }
+                        acc32[fa][fb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bitcast<f16x8>(a[k2 * (FC / 2) + fa]), bitcast<f16x8>(b[k2 * (FP / 2) + fb]),
+                                                                               acc32[fa][fb], 0, 0, 0);
         }
+    };
+    auto compute_half = [&](int stage, int ks) __attribute__((always_inline)) {
+        u32x4 a[FC], b[FP];
+        read_half(stage, ks, a, b);
+        mfma_half(a, b);
     };
 
     const int nk = p.ktiles;
-    if constexpr (DBG >= 3) stamp[1] = wall_clock64();
-    if constexpr (STAGES == 3) {
+    long long cyc = 0;
+    if constexpr (DBG >= 3) { stamp[1] = wall_clock64(); cyc = (long long)__builtin_readcyclecounter(); }
+    if constexpr (PIPE >= 1) {
+        // ---- staggered two-group loop (16 waves, 2 LDS stages).  Every wave alternates R(q) = read the fragments of half
+        // slab q from LDS and M(q) = its 16 MFMAs, one step per barrier interval; the waves (w/4) odd run one interval
+        // behind the others, so on every SIMD two waves multiply while the other two read (the matrix pipe never waits for
+        // the post-barrier LDS burst).  Interval i % 4 == 0 of slab t: every wave issues its DMA share of slab t+1 into the
+        // stage whose last reads ended two barriers earlier; interval i % 4 == 3: vmcnt(0), then the barrier publishes it.
+        static_assert(STAGES == 2 && NW == 16, "staggered loop: 16 waves, 2 stages");
+        issue_slab(0);
+        VMCNT(0);
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        const bool lag = (wave >> 2) & 1;          // wave-uniform: this wave runs one interval behind
+        u32x4 ra[FC], rb[FP];
+        auto R = [&](int stage, int ks) __attribute__((always_inline)) {
+            read_half(stage, ks, ra, rb);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        };
+        auto M = [&]() __attribute__((always_inline)) {
+            if constexpr (PIPE == 2) __builtin_amdgcn_s_setprio(1);
+            mfma_half(ra, rb);
+            if constexpr (PIPE == 2) __builtin_amdgcn_s_setprio(0);
+        };
+        auto BAR = [&]() __attribute__((always_inline)) {     // raw barrier; sched_barrier pins the (register-only) MFMAs to their interval
+            __builtin_amdgcn_sched_barrier(0); __builtin_amdgcn_s_barrier(); __builtin_amdgcn_sched_barrier(0);
+        };
+        // Both groups run the SAME instruction stream R(0) | M(0) | R(1) | M(1) ... (| = barrier); the lagging group takes one
+        // extra barrier before it and the leading group one after it.  Only the DMA issue points and the vmcnt(0) differ
+        // (they are tied to the global interval index): slab t+1 is issued in interval 4t, waited for in interval 4t+3.
+        if (lag) { if (nk > 1) issue_slab(1); BAR(); }
+        for (int t = 0; t < nk; ++t) {
+            const int st = t & 1;
+            if (!lag && t + 1 < nk) issue_slab(st ^ 1);        // lead: interval 4t
+            R(st, 0);
+            BAR();
+            M();
+            BAR();
+            R(st, 1);
+            if (lag) VMCNT(0);                                 // lag: interval 4t+3
+            BAR();
+            if (lag && t + 2 < nk) issue_slab(st);             // lag: interval 4(t+1); its own reads of stage st are done
+            M();
+            if (!lag) VMCNT(0);                                // lead: interval 4t+3
+            BAR();
+        }
+        if (!lag) BAR();
+    } else if constexpr (STAGES == 3) {
         // ---- 3-stage ring: slab t+1 stays in flight across the barrier of slab t (counted vmcnt, never 0 in the loop)
         issue_slab(0);
         if (nk > 1) issue_slab(1);
@@ -246,7 +304,7 @@ __global__ void __launch_bounds__(WC * WP * 64, WC * WP / 4) conv_dma_kernel(con
         }
     }
 
-    if constexpr (DBG >= 3) stamp[2] = wall_clock64();
+    if constexpr (DBG >= 3) { stamp[2] = wall_clock64(); cyc = (long long)__builtin_readcyclecounter() - cyc; }
     // ---- epilogue (identical math to conv_igemm.hip).  Thanks to the weight-row permutation every lane owns NG groups of
     // 8 consecutive output channels for each of its NPX pixels.  The epilogue runs as whole-register-set passes, each
     // behind ONE wave-uniform branch (out_scale / bias / residual / activation / post_scale), then 16-byte stores.
@@ -340,15 +398,15 @@ __global__ void __launch_bounds__(WC * WP * 64, WC * WP / 4) conv_dma_kernel(con
             o[0] = 0x7157a3b5ll; o[1] = stamp[0]; o[2] = stamp[1]; o[3] = stamp[2]; o[4] = stamp[3];
             o[5] = __builtin_amdgcn_s_getreg((31 << 11) | 4);    // HW_ID
             o[6] = __builtin_amdgcn_s_getreg((31 << 11) | 20);   // XCC_ID
-            o[7] = bid;
+            o[7] = cyc;                                          // shader cycles spent in the k-loop (s_memtime)
         }
     }
 }
 
-template <int BC, int BP, int WC, int WP, int STAGES, int MF = 16, int DBG = 0>
+template <int BC, int BP, int WC, int WP, int STAGES, int MF = 16, int DBG = 0, int PIPE = 0>
 static int launch_dma_cfg(const ConvArgs& a, hipStream_t st) {
     constexpr int LDS = STAGES * (BC + BP) * 128;
-    auto kern = conv_dma_kernel<BC, BP, WC, WP, STAGES, MF, DBG>;
+    auto kern = conv_dma_kernel<BC, BP, WC, WP, STAGES, MF, DBG, PIPE>;
     static thread_local bool attr_set = false;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
@@ -391,8 +449,9 @@ static int launch_dma_id(int id, const ConvArgs& a, hipStream_t st) {
         case 5: return launch_dma_cfg<64, 512, 1, 8, 2>(a, st);
         case 6: return launch_dma_cfg<256, 256, 2, 4, 2>(a, st);          // 8 waves, 128x64 per wave
         case 7: return launch_dma_cfg<256, 256, 4, 4, 2, 32>(a, st);
-        case 8: return launch_dma_cfg<128, 512, 2, 8, 2, 32>(a, st);
-        case 9: return launch_dma_cfg<64, 512, 1, 8, 2, 32>(a, st);
+        case 8: return launch_dma_cfg<256, 256, 4, 4, 2, 16, 0, 1>(a, st);  // staggered two-group loop
+        case 9: return launch_dma_cfg<256, 256, 4, 4, 2, 16, 0, 2>(a, st);  //   + s_setprio around the MFMA phase
+        case 10: return launch_dma_cfg<256, 256, 4, 4, 2, 32, 0, 1>(a, st); //   on 32x32x16
         case 11: return launch_dma_cfg<256, 256, 4, 4, 2, 16, 4>(a, st);  // DIAGNOSTIC: all tiles store over tile 0; stamps after tile 0
         case 12: return launch_dma_cfg<256, 256, 4, 4, 2, 16, 5>(a, st);  // DIAGNOSTIC: no output stores; stamps after tile 0
         case 13: return launch_dma_cfg<256, 256, 4, 4, 2, 16, 3>(a, st);  // DIAGNOSTIC: per-workgroup time stamps written over the output

@@ -16,7 +16,7 @@ sys.path.insert(0, ROOT)
 def report(name, st):
     ok = st[:, 0] == 0x7157a3b5
     st = st[ok]
-    t0, t1, t2, t3, hw, xcc = (st[:, i].astype(np.int64) for i in range(1, 7))
+    t0, t1, t2, t3, hw, xcc, cyc = (st[:, i].astype(np.int64) for i in range(1, 8))
     cu = ((hw >> 8) & 0xF) | (((hw >> 13) & 0x7) << 4) | (((hw >> 12) & 1) << 7) | ((xcc & 0xF) << 8)
     us = 0.01     # wall_clock64 ticks at 100 MHz
     print("%s: %d of %d workgroups stamped, %d distinct CU ids" % (name, ok.sum(), len(ok), len(np.unique(cu))))
@@ -29,7 +29,7 @@ def report(name, st):
         gaps.extend((t0[m][o][1:] - t3[m][o][:-1]).tolist())
     gaps = np.array(gaps)
     print("  gap between consecutive workgroups on a CU: mean %.2f us  p10 %.2f  p90 %.2f" % (gaps.mean() * us, np.percentile(gaps, 10) * us, np.percentile(gaps, 90) * us))
-    print("  kernel span %.1f us" % ((t3.max() - t0.min()) * us))
+    print("  kernel span %.1f us;  k-loop shader clock (s_memtime cycles / wall time): %.2f GHz" % ((t3.max() - t0.min()) * us, np.median(cyc / np.maximum(t2 - t1, 1)) / 10.0))
 
 
 def main():
@@ -41,7 +41,9 @@ def main():
         wt = ((torch.rand((cout, 3, 3, c), device=dev, generator=g) - 0.5) * 0.05).half()
         npix = n * h * w
         ntile = npix // 256
-        for cfg, label in ((13, "normal"), (11, "stores aliased onto tile 0"), (12, "no stores")):
+        for cfg, label in ((13, "normal"), (13, "normal, ZERO-FILLED operands"), (11, "stores aliased onto tile 0"), (12, "no stores")):
+            if "ZERO" in label:
+                x, wt = torch.zeros_like(x), torch.zeros_like(wt)
             for _ in range(2):
                 y = ops.conv2d(x, wt, cout, 3, 3, (1, 1), (1, 1), act=ops.ACT_LRELU, algo=16 + cfg)
             torch.cuda.synchronize()
