@@ -104,7 +104,9 @@ int mnet_conv2d_nhwc(const mnet_conv_desc* d, void* stream);
  *      of the register-staged kernel: every f16 launch yields the same bits whichever kernel / tile its size selects
  *   id 7/8/9: ids 0/4/5 on v_mfma_f32_32x32x16_f16 (experimental; fp32 partial sums associate differently)
  *   id 11-15: diagnostic builds used by tools/wg_timeline.py and tools/conv_bench.py; they produce WRONG results */
-enum { MNET_CONV_ALGO_AUTO = 0, MNET_CONV_ALGO_REG_STAGED = 1, MNET_CONV_ALGO_LDS_DMA = 2, MNET_CONV_ALGO_DMA_CFG0 = 16 };
+enum { MNET_CONV_ALGO_AUTO = 0, MNET_CONV_ALGO_REG_STAGED = 1, MNET_CONV_ALGO_LDS_DMA = 2, MNET_CONV_ALGO_DMA_CFG0 = 16,
+       MNET_CONV_ALGO_FLAG_ONE_TILE = 256 /* OR-ed in: LDS-DMA kernel launched with one workgroup per tile instead of its
+                                            * persistent grid (A/B measurements only; same results) */ };
 int mnet_conv2d_nhwc_ex(const mnet_conv_desc* d, int32_t algo, void* stream);
 
 /* which kernel `algo` resolves to for this launch, without launching: MNET_CONV_ALGO_REG_STAGED or

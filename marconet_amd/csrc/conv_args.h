@@ -11,7 +11,8 @@ struct ConvArgs {
     int kh, kw, sh, sw, ph, pw;
     int K, npix, howo;
     int in_swish, act, res_mod;
-    int ktiles, tilesC;
+    int ktiles, tilesC, ntiles;
+    int one_tile_per_wg;     // A/B knob (MNET_CONV_ALGO_FLAG_ONE_TILE): grid = #tiles instead of a persistent grid
 };
 
 // conv_igemm_dma.hip

@@ -320,6 +320,8 @@ extern "C" double mnet_conv2d_flops(const mnet_conv_desc* d) {
 
 // argument validation shared by the launch and the planning entry points; fills the kernel-argument block
 static int conv_prepare(const mnet_conv_desc* d, int32_t algo, ConvArgs& a) {
+    a.one_tile_per_wg = (algo & MNET_CONV_ALGO_FLAG_ONE_TILE) ? 1 : 0;
+    algo &= ~MNET_CONV_ALGO_FLAG_ONE_TILE;
     MNET_CHECK_ARG((algo >= 0 && algo <= 2) || (algo >= MNET_CONV_ALGO_DMA_CFG0 && algo < MNET_CONV_ALGO_DMA_CFG0 + 16),
                    "conv: bad algo %d", algo);
     MNET_CHECK_ARG(d != nullptr, "conv: null descriptor");
@@ -355,12 +357,13 @@ static int conv_prepare(const mnet_conv_desc* d, int32_t algo, ConvArgs& a) {
     a.K = d->kh * d->kw * a.cin; a.npix = (int)npix; a.howo = d->ho * d->wo;
     a.in_swish = d->in_swish; a.act = d->act; a.res_mod = d->res_mod;
     const int bk = d->dtype == MNET_F16 ? 64 : 32;
-    a.ktiles = (a.K + bk - 1) / bk; a.tilesC = 0;
+    a.ktiles = (a.K + bk - 1) / bk; a.tilesC = 0; a.ntiles = 0;
     return MNET_OK;
 }
 
 // resolves `algo` to the kernel that runs: MNET_CONV_ALGO_REG_STAGED or MNET_CONV_ALGO_DMA_CFG0 + id (negative: error)
 static int conv_resolve(const mnet_conv_desc* d, int32_t algo, const ConvArgs& a) {
+    algo &= ~MNET_CONV_ALGO_FLAG_ONE_TILE;
     const bool dma_ok = conv_dma_eligible(a, d->dtype);
     if (algo >= MNET_CONV_ALGO_LDS_DMA && !dma_ok)
         return mnet_fail(MNET_E_ARG, "conv: LDS-DMA algo needs f16, cin %% 64 == 0, cout >= 64, cout %% 8 == 0 and no input transform");

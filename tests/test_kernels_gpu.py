@@ -383,7 +383,7 @@ def test_conv_lds_dma_kernel(case):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("cfg", [0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10])
+@pytest.mark.parametrize("cfg", [0, 1, 2, 3, 4, 5, 6, 7, 8, 9])
 @pytest.mark.parametrize("shape", [(3, 40, 52, 64, 64, 200, 3), (700, 4, 4, 128, 0, 72, 3), (2, 9, 300, 192, 0, 320, 1)])
 def test_conv_lds_dma_every_tile_config(cfg, shape):
     """every LDS-DMA tile configuration, pinned explicitly, is bit-identical to the register-staged kernel on shapes with
@@ -404,7 +404,7 @@ def test_conv_lds_dma_every_tile_config(cfg, shape):
     y_cfg = ops.conv2d(x0, _pack_w(wt, dtype), cout, k, k, (1, 1), (k // 2, k // 2), algo=ALGO_DMA_CFG0 + cfg, **kw)
     y_reg = ops.conv2d(x0, _pack_w(wt, dtype), cout, k, k, (1, 1), (k // 2, k // 2), algo=1, **kw)
     torch.cuda.synchronize()
-    if cfg not in (7, 10):    # 16x16x32 MFMA, the register-staged kernel's k association → same bits for every tile config
+    if cfg < 7:    # 16x16x32 MFMA (production), the register-staged kernel's k association → same bits for every tile config
         assert torch.equal(y_cfg, y_reg), "LDS-DMA tile configuration %d differs from the register-staged kernel" % cfg
     else:          # 32x32x16 MFMA (experimental): same products, fp32 sums associated differently → equal up to f16 rounding
         d = (y_cfg.float() - y_reg.float()).abs()
