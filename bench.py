@@ -36,7 +36,8 @@ def parse():
     ap.add_argument("--batch", type=int, default=64, help="images per GPU (configs[1]: 64)")
     ap.add_argument("--glyphs", type=int, default=16, help="glyphs per image (SURVEY.md §8d: n=16)")
     ap.add_argument("--precision", default="fp16", choices=["fp16", "fp32"])
-    ap.add_argument("--cpu-images", type=int, default=1, help="images timed on the host CPU oracle (0 = skip)")
+    ap.add_argument("--cpu-images", type=int, default=4, help="images timed on the host CPU oracle (0 = skip); ~3.5 s each on 32 threads")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the secondary (no structure-image) throughput measurement")
     ap.add_argument("--cpu-threads", type=int, default=32, help="cap on host threads for the CPU baseline")
     ap.add_argument("--no-gather", action="store_true")
     return ap.parse_args()
@@ -102,6 +103,26 @@ def main():
         dt = float(t.item())
     assert torch.isfinite(y).all()
 
+    # ---- secondary figure (reported separately, never the headline): the same step without the generator's 128-px
+    # structure image, which only feeds test_sr.py's saved visualisation (SURVEY.md §7 "hard parts", last item)
+    secondary = None
+    if not a.no_secondary:
+        pipe.need_prior_image = False
+        step()
+        fence()
+        t0 = time.perf_counter()
+        for _ in range(a.steps):
+            step()
+        fence()
+        dt2 = time.perf_counter() - t0
+        pipe.need_prior_image = True
+        if world > 1:
+            t = torch.tensor([dt2], device=dev, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt2 = float(t.item())
+        secondary = {"images_per_s_without_prior_image": round(B * world * a.steps / dt2, 3), "ms_per_step": round(dt2 / a.steps * 1e3, 3),
+                     "note": "opt-in MarconetPipeline(need_prior_image=False): TSPGAN stops at the 64-px level; SR output identical"}
+
     # ---- roofline of the dominant kernel, from the live HIP events of the timed steps (events are recorded on the
     # launch stream around every conv launch; the kernel each launch resolved to comes from mnet_conv2d_plan)
     KNAME = {1: "conv_igemm_kernel (register-staged)", 16: "conv_dma_kernel<256,256,4,4,2,16>", 17: "conv_dma_kernel<256,128,4,2,3,16>",
@@ -162,6 +183,7 @@ def main():
                    "per_gpu_batch": B, "global_batch": B * world, "glyphs_per_image": n,
                    "parallelism": "dp%d" % world, "collective": "all_gather(SR outputs)" if world > 1 and not a.no_gather else "none"},
         "roofline": roofline,
+        "secondary": secondary,
     }
     roofline["end_to_end_frac_of_peak"] = round(out["value"] / world * (GF_F16_FIXED + GF_F16_PER_GLYPH * n + GF_FP32_VIT) / 1e3 / peak, 4)
 

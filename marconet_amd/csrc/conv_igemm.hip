@@ -307,7 +307,13 @@ static int launch_cfg(const ConvArgs& a, hipStream_t st) {
 
 template <typename T>
 static int launch_dtype(const ConvArgs& a, hipStream_t st) {
-    if (a.cout >= 128) return launch_cfg<T, 128, 128, 2, 2>(a, st);
+    // Small launches (the TextViT linears: 4096 x 512 outputs) would leave CUs idle with 128-channel tiles: halve the cout
+    // tile until the grid covers the CUs.  Every tile shape accumulates each output in the same k order, so
+    // the choice never changes a result bit.
+    const long long tilesP = (a.npix + 127) / 128;
+    if (a.cout >= 128 && tilesP * ((a.cout + 127) / 128) >= 512) return launch_cfg<T, 128, 128, 2, 2>(a, st);
+    if (a.cout >= 64 && (a.cout < 128 || tilesP * ((a.cout + 63) / 64) >= 256)) return launch_cfg<T, 64, 128, 2, 2>(a, st);
+    if (a.cout >= 128) return launch_cfg<T, 32, 128, 1, 4>(a, st);
     if (a.cout >= 64) return launch_cfg<T, 64, 128, 2, 2>(a, st);
     if (a.cout >= 32) return launch_cfg<T, 32, 128, 1, 4>(a, st);
     return launch_cfg<T, 16, 128, 1, 4>(a, st);

@@ -206,8 +206,10 @@ class TextGenerator(nn.Module):
             skip = ops.upsample2x(skip)                                        # :318-319
         return ops.conv2d(x, L["w"], RGB_PAD, in_scale=s, bias=L["bias"], residual=skip, act=ops.ACT_TANH)
 
-    def forward_nhwc(self, styles, labels):
-        """→ (image NHWC [N,128,128c,8], prior64 NHWC [N,64,64c,256], prior32 NHWC [N,32,32c,512])."""
+    def forward_nhwc(self, styles, labels, need_image=True):
+        """→ (image NHWC [N,128,128c,8], prior64 NHWC [N,64,64c,256], prior32 NHWC [N,32,32c,512]).
+        ``need_image=False`` (opt-in, batched SR driver only) stops after the 64-px level: the 128-px level feeds nothing
+        but the visualisation image (models/networks.py:148-164; 35 % of the generator's FLOPs) and ``image`` is None."""
         pk = self._cache.get(self, self.precision, self._build)
         dtype = torch_dtype(self.precision)
         lat = ops.pixelnorm(styles)                                            # :170-171
@@ -216,10 +218,12 @@ class TextGenerator(nn.Module):
         x = ops.embed_gather(pk["emb"], labels, dtype, self.class_num)         # SelectText (:205-215)
         s, d = self._style(pk["conv1"], lat)
         x = self._styled(pk["conv1"], x, s, d, premodulated=False)
-        skip = self._to_rgb(pk["rgb1"], x, lat, None)
+        skip = self._to_rgb(pk["rgb1"], x, lat, None) if need_image else None
         p64 = p32 = None
         nc = labels.shape[1]
         for lvl in range(len(pk["rgbs"])):
+            if not need_image and p64 is not None and p32 is not None:
+                return None, p64, p32
             La, Lb = pk["convs"][2 * lvl], pk["convs"][2 * lvl + 1]
             sa, da = self._style(La, lat)
             sb, db = self._style(Lb, lat)
@@ -228,7 +232,8 @@ class TextGenerator(nn.Module):
             del xu
             x = self._styled(Lb, xa, sb, db, premodulated=True)
             del xa
-            skip = self._to_rgb(pk["rgbs"][lvl], x, lat, skip)
+            if need_image:
+                skip = self._to_rgb(pk["rgbs"][lvl], x, lat, skip)
             if x.shape[2] == 64 * nc:
                 p64 = x
             if x.shape[2] == 32 * nc:

@@ -15,9 +15,12 @@ from .packing import torch_dtype
 
 
 class MarconetPipeline:
-    def __init__(self, encoder, gan, sr, precision="fp16", glyph_chunk=1024):
+    def __init__(self, encoder, gan, sr, precision="fp16", glyph_chunk=1024, need_prior_image=True):
         self.encoder, self.gan, self.sr = encoder, gan, sr
         self.glyph_chunk = glyph_chunk
+        # True (default): the generator also produces its 128-px structure image, as test_sr.py:183 does (it is only ever
+        # used for the saved visualisation, test_sr.py:203-232).  False is an opt-in for throughput serving.
+        self.need_prior_image = need_prior_image
         self.set_precision(precision)
 
     def set_precision(self, precision):
@@ -44,7 +47,8 @@ class MarconetPipeline:
             styles = w.index_select(0, img_of).contiguous()           # w0.repeat(n,1) per image (test_sr.py:183)
             p64s, p32s = [], []
             for s in range(0, lab.shape[0], self.glyph_chunk):        # bounded working set for huge batches
-                _, a, c = tg.forward_nhwc(styles[s:s + self.glyph_chunk].contiguous(), lab[s:s + self.glyph_chunk].contiguous())
+                _, a, c = tg.forward_nhwc(styles[s:s + self.glyph_chunk].contiguous(), lab[s:s + self.glyph_chunk].contiguous(),
+                                          need_image=self.need_prior_image)
                 p64s.append(a)
                 p32s.append(c)
             p64 = p64s[0] if len(p64s) == 1 else torch.cat(p64s)
@@ -53,6 +57,75 @@ class MarconetPipeline:
             p64 = p32 = None
         y = self.sr.forward_packed(lq, p64, p32, counts, counts, locs)   # test_sr.py:197
         return y if return_nhwc else ops.nhwc_to_nchw(y, c=3)
+
+
+    @torch.no_grad()
+    def forward_mixed_widths(self, lq, content_widths, labels, locs, bucket=64):
+        """BASELINE configs[4]: a batch of strips of different content widths (each zero-padded to 512, i.e. -1 after
+        Normalize, test_sr.py:100-115).  The encoder needs the 512-wide strip (its token-axis LayerNorm(64)/Linear(64,.)
+        pin 64 tokens, models/textvit_arch.py:59-62,141-144); TSPSRNet is width-agnostic, so images are bucketed by
+        ``ceil(w_b / bucket) * bucket`` and each bucket runs the SR net at its own width W' with ``locs`` re-normalised
+        to W' (locs are centre / width, models/networks.py:426).  SURVEY.md §8d: the oracle of this mode is the reference
+        TSPSRNet called at the same W' — it is NOT equal to the 512-padded run (GroupNorm reduces over the whole map).
+        → list (input order) of SR tensors [3, 128, 4·W'_b] fp32."""
+        dev = lq.device
+        B = lq.shape[0]
+        if lq.shape[-1] != 512 or len(content_widths) != B or len(labels) != B:
+            raise ValueError("forward_mixed_widths: lq must be [B,3,32,512] with one content width and one label list per image")
+        counts = [int(l.shape[0]) for l in labels]
+        widths = []
+        for w_ in content_widths:
+            w_ = int(w_)
+            if w_ <= 0 or w_ > 512:                      # the reference skips wider strips (test_sr.py:108-110)
+                raise ValueError("content width %d outside (0, 512]: split the strip into <=512-px segments" % w_)
+            widths.append(min(512, (w_ + bucket - 1) // bucket * bucket))
+        _, _, w = self.encoder(lq)
+        tg = self.gan.TextGenerator
+        tg.precision = self.precision
+        starts = [0]
+        for c in counts:
+            starts.append(starts[-1] + c)
+        p64 = p32 = None
+        if starts[-1]:
+            lab = torch.cat([l.reshape(-1, 1) for l in labels if l.shape[0]], dim=0).to(dev).long().contiguous()
+            if int(lab.min()) < 0 or int(lab.max()) >= tg.class_num:
+                raise RuntimeError("label index out of range [0,%d)" % tg.class_num)
+            img_of = torch.repeat_interleave(torch.arange(B, device=dev), torch.tensor(counts, device=dev))
+            _, p64, p32 = tg.forward_nhwc(w.index_select(0, img_of).contiguous(), lab, need_image=self.need_prior_image)
+        out = [None] * B
+        for wb in sorted(set(widths)):
+            idx = [b for b in range(B) if widths[b] == wb]
+            gsel = [g for b in idx for g in range(starts[b], starts[b + 1])]
+            cb = [counts[b] for b in idx]
+            it = torch.tensor(idx, device=dev)
+            lq_b = lq.index_select(0, it)[:, :, :, :wb].contiguous()
+            locs_b = (locs.index_select(0, it).float() * (512.0 / wb)).contiguous()
+            if gsel:
+                gt = torch.tensor(gsel, device=dev)
+                a, c = p64.index_select(0, gt), p32.index_select(0, gt)
+            else:
+                a = c = None
+            y = ops.nhwc_to_nchw(self.sr.forward_packed(lq_b, a, c, cb, cb, locs_b), c=3)
+            for k, b in enumerate(idx):
+                out[b] = y[k]
+        return out
+
+
+def balance_shards(content_widths, glyph_counts, world, bucket=64):
+    """configs[4] on N GPUs: assign images to ranks so that the algorithmic work per rank is balanced
+    (longest-processing-time greedy on F_b = 108.0 + 3.69 + 484.1·W'_b/512 + 89.03·n_b GFLOP).
+    → list of ``world`` index lists (each sorted by bucket width so a rank runs few distinct widths)."""
+    cost = []
+    for b, (w_, n) in enumerate(zip(content_widths, glyph_counts)):
+        wb = min(512, (int(w_) + bucket - 1) // bucket * bucket)
+        cost.append((108.0 + 3.69 + 484.1 * wb / 512.0 + 89.03 * int(n), wb, b))
+    load = [0.0] * world
+    parts = [[] for _ in range(world)]
+    for c, wb, b in sorted(cost, reverse=True):
+        r = min(range(world), key=lambda k: (load[k], k))
+        load[r] += c
+        parts[r].append((wb, b))
+    return [[b for _, b in sorted(p_)] for p_ in parts]
 
 
 def shard_range(total, rank, world):

@@ -71,3 +71,18 @@ def test_shard_range_partitions_exactly():
             assert all(spans[i][1] == spans[i + 1][0] for i in range(world - 1))
             sizes = [b - a for a, b in spans]
             assert max(sizes) - min(sizes) <= 1
+
+
+def test_balance_shards_for_mixed_widths():
+    """configs[4]: every image lands on exactly one rank and the per-rank algorithmic work is balanced to within one image"""
+    import random
+    from marconet_amd.pipeline import balance_shards
+    rng = random.Random(3)
+    widths = [rng.choice([128, 192, 256, 320, 384, 448, 512]) - rng.randint(0, 40) for _ in range(203)]
+    counts = [rng.randint(0, 16) for _ in widths]
+    f = lambda b: 108.0 + 3.69 + 484.1 * min(512, (widths[b] + 63) // 64 * 64) / 512.0 + 89.03 * counts[b]
+    for world in (1, 2, 4, 8):
+        parts = balance_shards(widths, counts, world)
+        assert sorted(b for p_ in parts for b in p_) == list(range(len(widths)))
+        loads = [sum(f(b) for b in p_) for p_ in parts]
+        assert max(loads) - min(loads) <= max(f(b) for b in range(len(widths))) + 1e-9

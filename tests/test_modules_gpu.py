@@ -217,3 +217,73 @@ def test_fused_act_provider_is_hip():
     with torch.no_grad():
         m.bias.copy_(b)
     assert _err(m(x.to(DEV)), O.fused_leaky_relu(x, b)) <= 1e-6
+
+
+def test_pipeline_without_prior_image_gives_identical_sr(nets, ckpts):
+    """the opt-in need_prior_image=False driver mode (secondary bench figure) must not change a single SR bit"""
+    from marconet_amd.pipeline import MarconetPipeline
+    lq = synth.make_lq(31, 2, [512, 300]).to(DEV)
+    labels = [synth.make_labels(32, 5).to(DEV), synth.make_labels(33, 3).to(DEV)]
+    locs = synth.make_locs([5, 3], [512, 300]).to(DEV)
+    pipe = MarconetPipeline(*nets, precision="fp16")
+    y1 = pipe.forward_batch(lq, labels, locs)
+    pipe.need_prior_image = False
+    y0 = pipe.forward_batch(lq, labels, locs)
+    pipe.set_precision("fp32")
+    assert torch.equal(y0, y1) and torch.isfinite(y1).all()
+
+
+def test_config4_gan_only_large_batch(nets, ckpts):
+    """BASELINE configs[3] (test_w.py path): TSPGAN alone on a large glyph batch, one style per 16-glyph group
+    (test_w.py:104-108).  fp32 parity on a subset against the oracle; the fp16 run of the full 256 x 16 batch must be
+    finite, tanh-bounded and equal (bit for bit) to the same glyphs run in a small batch (batch invariance)."""
+    gan = nets[1]
+    groups, n = 256, 16
+    styles = synth.make_styles(41, groups).repeat_interleave(n, dim=0)
+    labels = synth.make_labels(42, groups * n)
+    with torch.no_grad():
+        ref = O.tspgan_forward(ckpts[1], styles[:2 * n], labels[:2 * n])
+    gan.set_precision("fp32")
+    img, p64, p32 = gan(styles=styles[:2 * n].to(DEV), labels=labels[:2 * n].to(DEV), noise=None)
+    for name, got, want in (("image", img, ref[0]), ("prior64", p64, ref[1]), ("prior32", p32, ref[2])):
+        e = _err(got, want)
+        _note("gan.cfg4.fp32.%s.maxabs" % name, e)
+        assert e <= TOL
+    gan.set_precision("fp16")
+    tg = gan.TextGenerator
+    big = tg.forward_nhwc(styles.to(DEV), labels.to(DEV))
+    small = tg.forward_nhwc(styles[:n].to(DEV).contiguous(), labels[:n].to(DEV).contiguous())
+    torch.cuda.synchronize()
+    assert big[0].shape == (groups * n, 128, 128, 8) and torch.isfinite(big[0]).all() and float(big[0].abs().max()) <= 1.0
+    for b_, s_ in zip(big, small):
+        assert torch.equal(b_[:n], s_)
+    gan.set_precision("fp32")
+
+
+def test_config5_mixed_widths_bucketed(nets, ckpts):
+    """BASELINE configs[4]: variable-width strips bucketed by padded width.  Oracle: the reference
+    TSPSRNet at the SAME bucket width with locs re-normalised to it; encoder and TSPGAN see the 512-padded strip."""
+    from marconet_amd.pipeline import MarconetPipeline
+    widths = [130, 200, 512, 250, 128]
+    counts = [2, 3, 4, 0, 1]
+    lq = synth.make_lq(51, len(widths), widths)
+    labels = [synth.make_labels(60 + i, c) for i, c in enumerate(counts)]
+    locs = synth.make_locs(counts, widths)
+    pipe = MarconetPipeline(*nets, precision="fp32")
+    outs = pipe.forward_mixed_widths(lq.to(DEV), widths, [l.to(DEV) for l in labels], locs.to(DEV))
+    worst = 0.0
+    with torch.no_grad():
+        _, _, w = O.encoder_forward(ckpts[0], lq)
+        for b, wd in enumerate(widths):
+            wb = (wd + 63) // 64 * 64
+            if counts[b]:
+                _, a, c = O.tspgan_forward(ckpts[1], w[b:b + 1].repeat(counts[b], 1), labels[b])
+            else:
+                a, c = torch.zeros(0, 256, 64, 64), torch.zeros(0, 512, 32, 32)
+            ref = O.tspsr_forward(ckpts[2], lq[b:b + 1, :, :, :wb], [a], [c], locs[b:b + 1] * (512.0 / wb))
+            assert outs[b].shape == (3, 128, 4 * wb)
+            worst = max(worst, _err(outs[b], ref[0]))
+    _note("sr.cfg5.fp32.bucketed.maxabs", worst)
+    assert worst <= TOL
+    with pytest.raises(ValueError):
+        pipe.forward_mixed_widths(lq.to(DEV), [640] + widths[1:], [l.to(DEV) for l in labels], locs.to(DEV))
