@@ -100,9 +100,10 @@ int mnet_conv2d_nhwc(const mnet_conv_desc* d, void* stream);
  * register-staged one otherwise; MNET_CONV_ALGO_DMA_CFG0 + id pins one LDS-DMA tile configuration
  * (cout x pixel tile, waves, LDS stages):
  *   id 0: 256x256 16w 2st   1: 256x128 8w 3st   2: 128x256 8w 3st   3: 64x256 8w 3st   4: 128x512 16w 2st
- *      5: 64x512 8w 2st     6: 256x256 8w 2st (128x64 per wave)      — all on v_mfma_f32_16x16x32_f16 with the k association
- *      of the register-staged kernel: every f16 launch yields the same bits whichever kernel / tile its size selects
- *   id 7/8/9: ids 0/4/5 on v_mfma_f32_32x32x16_f16 (experimental; fp32 partial sums associate differently)
+ *      5: 64x512 8w 2st     6: 256x256 8w 2st (128x64 per wave)      — all on v_mfma_f32_16x16x32_f16 walking k in the
+ *      same order (64-channel slice outer, filter tap inner): the same bits for every launch size (batch-invariant);
+ *      the register-staged kernel walks k tap-outer (same products, fp32 partial sums associated differently)
+ *   id 7/8/9: ids 0/4/5 on v_mfma_f32_32x32x16_f16 (experimental)
  *   id 11-15: diagnostic builds used by tools/wg_timeline.py and tools/conv_bench.py; they produce WRONG results */
 enum { MNET_CONV_ALGO_AUTO = 0, MNET_CONV_ALGO_REG_STAGED = 1, MNET_CONV_ALGO_LDS_DMA = 2, MNET_CONV_ALGO_DMA_CFG0 = 16,
        MNET_CONV_ALGO_FLAG_ONE_TILE = 256 /* OR-ed in: LDS-DMA kernel launched with one workgroup per tile instead of its

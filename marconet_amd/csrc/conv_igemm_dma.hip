@@ -42,7 +42,7 @@ __device__ __forceinline__ void store8(const ConvArgs& p, const float* v, int pi
     stg16(reinterpret_cast<f16*>(p.y) + (size_t)pix * p.cout + co, Vec<f16>::pack(v));
 }
 
-// MF = 16: v_mfma_f32_16x16x32_f16 — production (same k association as conv_igemm.hip → bit-identical to it);
+// MF = 16: v_mfma_f32_16x16x32_f16 — production;
 // MF = 32: v_mfma_f32_32x32x16_f16 — experimental (half the matrix instructions per slab; not faster here: the kernel is
 //          power/clock limited)
 template <int BC, int BP, int WC, int WP, int STAGES, int MF = 16, int DBG = 0>
@@ -156,7 +156,10 @@ __global__ void __launch_bounds__(WC * WP * 64, WC * WP / 4) conv_dma_kernel(con
     auto issue_slab = [&](int stage) __attribute__((always_inline)) {
         unsigned char* sw_ = smem + stage * STAGE;
         unsigned char* sx_ = sw_ + BC * 128;
-        const unsigned kb = (unsigned)cur_k * 2u;
+        // k-slab order: 64-channel slice OUTER, filter tap INNER — the 9 taps of a 3x3 filter re-read the same three input
+        // rows of one 64-channel slice back to back (≈100 KB per tile) instead of coming back to them after a pass over all
+        // channels, so the re-reads, and the rows shared with the vertically neighbouring tiles, hit in the XCD's L2.
+        const unsigned kb = (unsigned)(cur_tap * p.cin + cur_c) * 2u;
         if constexpr (DBG == 2) { if (cur_k > 0) { cur_k += 64; return; } }   // DIAGNOSTIC: no DMA after a tile's first slab
         const __amdgpu_buffer_rsrc_t rW = __builtin_amdgcn_make_buffer_rsrc((void*)uni64(bW), 0, __builtin_amdgcn_readfirstlane(nW), 0x00020000);
 #pragma unroll
@@ -183,11 +186,9 @@ __global__ void __launch_bounds__(WC * WP * 64, WC * WP / 4) conv_dma_kernel(con
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(rX0, (lds_void*)(sx_ + (wave + NW * j) * 1024), 16, vo, 0, 0, 0);
             }
         }
-        cur_k += 64; cur_c += 64;
-        if (cur_c == p.cin) {
-            cur_c = 0; ++cur_tap;
-            if (++cur_s == p.kw) { cur_s = 0; cur_tpx += p.w - (p.kw - 1); } else { ++cur_tpx; }
-        }
+        cur_k += 64; ++cur_tap;
+        if (++cur_s == p.kw) { cur_s = 0; cur_tpx += p.w - (p.kw - 1); } else { ++cur_tpx; }
+        if (cur_tap == p.kh * p.kw) { cur_tap = 0; cur_s = 0; cur_tpx = 0; cur_c += 64; }
     };
 
     int i_v = blockIdx.x, i_kt = 0, i_stage = 0;         // head of the slab stream: tile, slab, LDS stage
@@ -436,8 +437,10 @@ static int launch_dma_cfg(const ConvArgs& a, hipStream_t st) {
 }
 
 // tile configurations (BC x BP, waves, LDS stages, MFMA shape); MNET_CONV_ALGO_DMA_CFG0 + id selects one explicitly.
-// Production ids 0-6 all use v_mfma_f32_16x16x32_f16 with the register-staged kernel's k association, so every f16 conv
-// launch gives the same bits whatever kernel / tile configuration its size selects (batch-size-invariant results).
+// Production ids 0-6 all use v_mfma_f32_16x16x32_f16 and walk k in the same order (64-channel slice outer, tap inner), so a
+// conv gives the same bits whatever tile configuration its launch size selects (batch-size-invariant results; eligibility
+// for this kernel never depends on the batch size).  The register-staged kernel walks k tap-outer: same products, fp32
+// partial sums associated differently.
 // ids 7-9: v_mfma_f32_32x32x16_f16 forms (fp32 sums associate differently).
 // ids 11-15: DIAGNOSTIC builds that produce wrong results on purpose (tools/wg_timeline.py, tools/conv_bench.py).
 static int launch_dma_id(int id, const ConvArgs& a, hipStream_t st) {

@@ -352,8 +352,7 @@ DMA_CASES = [
 
 @pytest.mark.parametrize("case", DMA_CASES)
 def test_conv_lds_dma_kernel(case):
-    """the LDS-DMA fast path: against F.conv2d and bit-for-bit against the register-staged kernel
-    (same k order and MFMA shape → identical fp32 accumulation)."""
+    """the LDS-DMA fast path: against F.conv2d and, to f16 output rounding, against the register-staged kernel"""
     ops = _ops()
     dtype = torch.float16
     n, h, w, c0, c1, cout, k, stride, pad = case
@@ -379,7 +378,8 @@ def test_conv_lds_dma_kernel(case):
     y_reg = ops.conv2d(x0, _pack_w(wt, dtype), cout, k, k, stride, (pad, pad), algo=1, **kw)
     torch.cuda.synchronize()
     _check("conv LDS-DMA %s" % (case,), _nchw(y_dma), ref, dtype, extra=2.0)
-    assert torch.equal(y_dma, y_reg), "LDS-DMA and register-staged kernels must agree bit for bit"
+    d = (y_dma.float() - y_reg.float()).abs()     # k walked in a different order: fp32 partial sums associate differently
+    assert float(d.max()) <= 2.0 ** -9 * float(y_reg.float().abs().max())
 
 
 @pytest.mark.gpu
@@ -404,12 +404,13 @@ def test_conv_lds_dma_every_tile_config(cfg, shape):
     y_cfg = ops.conv2d(x0, _pack_w(wt, dtype), cout, k, k, (1, 1), (k // 2, k // 2), algo=ALGO_DMA_CFG0 + cfg, **kw)
     y_reg = ops.conv2d(x0, _pack_w(wt, dtype), cout, k, k, (1, 1), (k // 2, k // 2), algo=1, **kw)
     torch.cuda.synchronize()
-    if cfg < 7:    # 16x16x32 MFMA (production), the register-staged kernel's k association → same bits for every tile config
-        assert torch.equal(y_cfg, y_reg), "LDS-DMA tile configuration %d differs from the register-staged kernel" % cfg
-    else:          # 32x32x16 MFMA (experimental): same products, fp32 sums associated differently → equal up to f16 rounding
-        d = (y_cfg.float() - y_reg.float()).abs()
-        assert float(d.max()) <= 2.0 ** -9 * float(y_reg.float().abs().max()), "cfg %d: max diff %g" % (cfg, float(d.max()))
-        assert float((d > 0).float().mean()) < 0.2
+    # same products as the register-staged kernel, fp32 partial sums associated differently (k order / MFMA shape)
+    d = (y_cfg.float() - y_reg.float()).abs()
+    assert float(d.max()) <= 2.0 ** -9 * float(y_reg.float().abs().max()), "cfg %d: max diff %g" % (cfg, float(d.max()))
+    assert float((d > 0).float().mean()) < 0.2
+    if cfg < 7:    # production configurations: bit-identical to each other (what makes results independent of the batch size)
+        y_auto = ops.conv2d(x0, _pack_w(wt, dtype), cout, k, k, (1, 1), (k // 2, k // 2), algo=2, **kw)
+        assert torch.equal(y_cfg, y_auto), "tile configuration %d differs from the auto-picked configuration" % cfg
 
 
 def test_conv_lds_dma_eligibility():
