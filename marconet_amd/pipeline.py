@@ -111,6 +111,54 @@ class MarconetPipeline:
         return out
 
 
+    @torch.no_grad()
+    def forward_blind(self, lq, max_glyphs=16):
+        """Self-contained end-to-end pass (SURVEY.md §8f NEXT-2): labels and glyph locations come from the encoder itself
+        instead of the YOLO + OCR front-end — labels = ``clear_labels(logits)`` (test_w.py:34-40), locs = the encoder's
+        (left, right) pairs converted to (centre, half-width) (Train/tspgan/models/tspgan_model.py:331-336).
+        → (SR [B,3,128,2048], labels list, locs [B,32])."""
+        logits, locs_lr, _ = self.encoder(lq)
+        labels = clear_labels_batch(logits)
+        labels = [l[:max_glyphs] for l in labels]
+        locs = locs_from_left_right(locs_lr)
+        return self.forward_batch(lq, [l.to(lq.device) for l in labels], locs), labels, locs
+
+
+ALPHABET_SIZE = 6735          # utils/alphabets.py: 6735 characters; class 6735 = blank / padding
+
+
+def clear_labels_batch(logits):
+    """test_w.py:34-40 for a whole batch: argmax over the 6736 classes (HIP kernel, first maximal index like torch.max),
+    ONE device→host copy of the [B,64] indices, then the CTC-style collapse on the host (drop repeats, drop blanks).
+    → list of B int64 tensors [n_b, 1] (CPU)."""
+    B, T, C = logits.shape
+    idx = ops.argmax_rows(logits.reshape(B * T, C).contiguous().float()).reshape(B, T).cpu().tolist()
+    out = []
+    for row in idx:
+        keep = [v for i, v in enumerate(row) if not (i > 0 and row[i - 1] == v) and v < ALPHABET_SIZE]
+        out.append(torch.tensor(keep, dtype=torch.int64).reshape(-1, 1))
+    return out
+
+
+def locs_from_left_right(locs_lr):
+    """(left, right) pairs → (centre, half-width) pairs, Train/tspgan/models/tspgan_model.py:331-336 (elementwise; tiny)."""
+    l, r = locs_lr[:, 0::2], locs_lr[:, 1::2]
+    out = torch.empty_like(locs_lr)
+    out[:, 0::2] = (r + l) / 2.0
+    out[:, 1::2] = (r - l) / 2.0
+    return out
+
+
+@torch.no_grad()
+def w_interpolation(gan, w1, w2, labels, steps=11):
+    """test_w.py:104-108: structure images for styles s·w1 + (1-s)·w2, s = i/(steps-1) — all interpolation steps in ONE
+    generator call (each glyph is independent).  w1, w2 [1,512]; labels int64 [n,1] → images [steps, n, 3, 128, 128]."""
+    n = labels.shape[0]
+    ws = torch.cat([(w1 * (i / (steps - 1)) + w2 * (1 - i / (steps - 1))).repeat(n, 1) for i in range(steps)], dim=0)
+    img, _, _ = gan(styles=ws.contiguous(), labels=labels.to(w1.device).repeat(steps, 1), noise=None)
+    return img.reshape(steps, n, *img.shape[1:])
+
+
 def balance_shards(content_widths, glyph_counts, world, bucket=64):
     """configs[4] on N GPUs: assign images to ranks so that the algorithmic work per rank is balanced
     (longest-processing-time greedy on F_b = 108.0 + 3.69 + 484.1·W'_b/512 + 89.03·n_b GFLOP).

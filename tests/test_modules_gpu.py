@@ -287,3 +287,34 @@ def test_config5_mixed_widths_bucketed(nets, ckpts):
     assert worst <= TOL
     with pytest.raises(ValueError):
         pipe.forward_mixed_widths(lq.to(DEV), [640] + widths[1:], [l.to(DEV) for l in labels], locs.to(DEV))
+
+
+def test_clear_labels_locs_and_w_interpolation(nets, ckpts):
+    """test_w.py path: argmax + collapse on our logits == the oracle's clear_labels on its logits (bit-exact indices),
+    (left,right)→(centre,half-width), and the batched w-interpolation == one generator call per step."""
+    from marconet_amd.pipeline import clear_labels_batch, locs_from_left_right, w_interpolation
+    lq = synth.make_lq(71, 2, [290, 255])
+    with torch.no_grad():
+        ref_logits, ref_locs, ref_w = O.encoder_forward(ckpts[0], lq)
+    logits, locs_lr, w = nets[0](lq.to(DEV))
+    got = clear_labels_batch(logits)
+    for b in range(2):
+        assert got[b].reshape(-1).tolist() == O.clear_labels(ref_logits[b])
+    conv = locs_from_left_right(locs_lr).cpu()
+    assert torch.allclose(conv[:, 0::2], (ref_locs[:, 1::2] + ref_locs[:, 0::2]) / 2, atol=1e-5)
+    assert torch.allclose(conv[:, 1::2], (ref_locs[:, 1::2] - ref_locs[:, 0::2]) / 2, atol=1e-5)
+    labels = got[0][:3] if got[0].shape[0] >= 1 else synth.make_labels(72, 3)
+    imgs = w_interpolation(nets[1], w[:1], w[1:2], labels, steps=3)
+    for i in range(3):
+        s_ = i / 2
+        with torch.no_grad():
+            ref = O.tspgan_forward(ckpts[1], (ref_w[:1] * s_ + ref_w[1:2] * (1 - s_)).repeat(labels.shape[0], 1), labels)[0]
+        assert _err(imgs[i], ref) <= TOL
+
+
+def test_forward_blind_runs_end_to_end(nets):
+    from marconet_amd.pipeline import MarconetPipeline
+    pipe = MarconetPipeline(*nets, precision="fp32")
+    lq = synth.make_lq(81, 2, [400, 512]).to(DEV)
+    sr, labels, locs = pipe.forward_blind(lq)
+    assert sr.shape == (2, 3, 128, 2048) and torch.isfinite(sr).all() and len(labels) == 2 and locs.shape == (2, 32)
