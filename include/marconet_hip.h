@@ -106,12 +106,17 @@ int mnet_conv2d_nhwc(const mnet_conv_desc* d, void* stream);
  *   id 7/8/9: ids 0/4/5 on v_mfma_f32_32x32x16_f16 (experimental)
  *   id 11-15: diagnostic builds used by tools/wg_timeline.py and tools/conv_bench.py; they produce WRONG results */
 enum { MNET_CONV_ALGO_AUTO = 0, MNET_CONV_ALGO_REG_STAGED = 1, MNET_CONV_ALGO_LDS_DMA = 2, MNET_CONV_ALGO_DMA_CFG0 = 16,
+       MNET_CONV_ALGO_STRIP_CFG0 = 32 /* + id: the 3x3 "strip" LDS-DMA kernel (one activation strip per filter row shared by its
+                                        * three taps; id 0: 256x256 tile, id 1: 64x512 tile).  Eligible: 3x3/stride 1/pad 1, one
+                                        * source, cout >= 256 (id 0) or < 128 (id 1), >= 65536 output pixels, whole-row tiles.
+                                        * AUTO uses id 1 when eligible (id 0 measured neutral: explicit request only).  Same k order and MFMA as the LDS-DMA kernel → identical bits. */,
        MNET_CONV_ALGO_FLAG_ONE_TILE = 256 /* OR-ed in: LDS-DMA kernel launched with one workgroup per tile instead of its
                                             * persistent grid (A/B measurements only; same results) */ };
 int mnet_conv2d_nhwc_ex(const mnet_conv_desc* d, int32_t algo, void* stream);
 
 /* which kernel `algo` resolves to for this launch, without launching: MNET_CONV_ALGO_REG_STAGED or
- * MNET_CONV_ALGO_DMA_CFG0 + id; negative MNET_E_* on invalid arguments (bench.py buckets its timings by this) */
+ * MNET_CONV_ALGO_DMA_CFG0 + id or MNET_CONV_ALGO_STRIP_CFG0 + id; negative MNET_E_* on invalid arguments (bench.py buckets
+ * its timings by this) */
 int mnet_conv2d_plan(const mnet_conv_desc* d, int32_t algo);
 
 /* 2*MACs of the launch described by d (for roofline accounting in bench.py) */

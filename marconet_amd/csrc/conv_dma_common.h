@@ -1,0 +1,140 @@
+// Pieces shared by the two LDS-DMA convolution kernels (conv_igemm_dma.hip: one k-slab of activations per filter tap;
+// conv_strip_dma.hip: one activation strip per filter row, reused by its three taps).
+#pragma once
+#include <cstdlib>
+#include "common.h"
+#include "conv_args.h"
+
+typedef __attribute__((address_space(3))) void lds_void;
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+// LDS image of a [rows][128 B] operand tile: 16-byte chunk c of row r lives at chunk c ^ ((r >> 1) & 7)
+__device__ __forceinline__ int swz_dma(int row, int chunk) { return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4); }
+
+#define VMCNT(n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
+
+// store 8 consecutive output channels co..co+7 of pixel `pix` (DBG: diagnostic variants, see launch_dma_id)
+template <int DBG>
+__device__ __forceinline__ void store8(const ConvArgs& p, const float* v, int pix, int co) {
+    if constexpr (DBG == 5) {           // DIAGNOSTIC: no stores (values kept live)
+        asm volatile("" :: "v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]), "v"(v[4]), "v"(v[5]), "v"(v[6]), "v"(v[7]));
+        return;
+    }
+    if constexpr (DBG == 4) pix &= 255;  // DIAGNOSTIC: every tile stores over tile 0 (L2-resident writes)
+    stg16(reinterpret_cast<f16*>(p.y) + (size_t)pix * p.cout + co, Vec<f16>::pack(v));
+}
+
+// weight row permutation applied on the DMA source side: LDS row `row` of the weight tile holds output channel
+// (tile base +) dma_weight_channel(row), chosen so that the MFMA fragments of a lane together hold 8 CONSECUTIVE channels
+//   MF = 16: LDS row 64b + 16f + i holds channel 64b + 32(f/2) + 8(i/4) + 4(f%2) + i%4
+//   MF = 32: LDS row 32b + i (D row i = 8q + 4h + e of lane-half h) holds channel 32b + 16h + 4q + e
+template <int MF>
+__device__ __forceinline__ int dma_weight_channel(int row) {
+    if constexpr (MF == 16) {
+        const int f = (row >> 4) & 3, i = row & 15;
+        return (row & ~63) + ((f >> 1) << 5) + ((i >> 2) << 3) + ((f & 1) << 2) + (i & 3);
+    } else {
+        const int i = row & 31;
+        return (row & ~31) + (((i >> 2) & 1) << 4) + ((i >> 3) << 2) + (i & 3);
+    }
+}
+
+// Epilogue of one (cout tile co0, pixel tile pix0): identical math to conv_igemm.hip.  Every lane owns NG groups of 8
+// consecutive output channels for each of its NPX pixels; whole-register-set passes, each behind ONE wave-uniform branch
+// (out_scale / bias / residual / activation / post_scale), then 16-byte stores.
+template <int BC, int BP, int WC, int WP, int MF, int DBG, int FC, int FP>
+__device__ __forceinline__ void dma_epilogue(const ConvArgs& p, const f32x4 (&acc)[FC][FP],
+                                             const f32x16 (&acc32)[MF == 32 ? FC / 2 : 1][MF == 32 ? FP / 2 : 1],
+                                             int co0, int pix0, int wc, int wp, int lane) {
+    const int l16 = lane & 15, g = lane >> 4;
+    constexpr int NPX = MF == 16 ? FP : FP / 2;          // pixels per lane
+    constexpr int NG = MF == 16 ? FC / 2 : FC;           // 8-channel groups per pixel per lane
+    float ev[NPX][NG][8];
+    int epix[NPX], eco[NG];
+#pragma unroll
+    for (int gi = 0; gi < NG; ++gi)
+        eco[gi] = MF == 16 ? co0 + wc * (BC / WC) + gi * 32 + g * 8
+                           : co0 + wc * (BC / WC) + (gi >> 1) * 32 + (lane >> 5) * 16 + (gi & 1) * 8;
+#pragma unroll
+    for (int px = 0; px < NPX; ++px) {
+        epix[px] = MF == 16 ? pix0 + wp * (BP / WP) + px * 16 + l16 : pix0 + wp * (BP / WP) + px * 32 + (lane & 31);
+#pragma unroll
+        for (int gi = 0; gi < NG; ++gi)
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                if constexpr (MF == 16) ev[px][gi][q] = acc[2 * gi + (q >> 2)][px][q & 3];
+                else ev[px][gi][q] = acc32[gi >> 1][px][(gi & 1) * 8 + q];
+            }
+    }
+    const int last_pix = p.npix - 1;
+    if (p.out_scale) {
+#pragma unroll
+        for (int px = 0; px < NPX; ++px) {
+            const float* sp = p.out_scale + (size_t)(min(epix[px], last_pix) / p.howo) * p.cout;
+#pragma unroll
+            for (int gi = 0; gi < NG; ++gi) {
+                if (eco[gi] >= p.cout) continue;
+                const f32x4 s0 = *reinterpret_cast<const f32x4*>(sp + eco[gi]), s1 = *reinterpret_cast<const f32x4*>(sp + eco[gi] + 4);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) { ev[px][gi][q] *= s0[q]; ev[px][gi][4 + q] *= s1[q]; }
+            }
+        }
+    }
+    if (p.bias) {
+#pragma unroll
+        for (int gi = 0; gi < NG; ++gi) {
+            if (eco[gi] >= p.cout) continue;
+            const f32x4 b0 = *reinterpret_cast<const f32x4*>(p.bias + eco[gi]), b1 = *reinterpret_cast<const f32x4*>(p.bias + eco[gi] + 4);
+#pragma unroll
+            for (int px = 0; px < NPX; ++px)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) { ev[px][gi][q] += b0[q]; ev[px][gi][4 + q] += b1[q]; }
+        }
+    }
+    if (p.res) {
+        const f16* rs = reinterpret_cast<const f16*>(p.res);
+#pragma unroll
+        for (int px = 0; px < NPX; ++px) {
+            if (epix[px] >= p.npix) continue;
+            const int rpix = p.res_mod > 0 ? epix[px] % p.res_mod : epix[px];
+#pragma unroll
+            for (int gi = 0; gi < NG; ++gi) {
+                if (eco[gi] >= p.cout) continue;
+                const f16x8 r8 = bitcast<f16x8>(ldg16(rs + (size_t)rpix * p.cout + eco[gi]));
+#pragma unroll
+                for (int q = 0; q < 8; ++q) ev[px][gi][q] += (float)r8[q];
+            }
+        }
+    }
+    act_apply_vec<NPX * NG * 8, true>(&ev[0][0][0], p.act);     // this path only takes the cheap (branch-free) activations
+    if (p.post_scale) {
+#pragma unroll
+        for (int px = 0; px < NPX; ++px) {
+            const float* sp = p.post_scale + (size_t)(min(epix[px], last_pix) / p.howo) * p.cout;
+#pragma unroll
+            for (int gi = 0; gi < NG; ++gi) {
+                if (eco[gi] >= p.cout) continue;
+                const f32x4 s0 = *reinterpret_cast<const f32x4*>(sp + eco[gi]), s1 = *reinterpret_cast<const f32x4*>(sp + eco[gi] + 4);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) { ev[px][gi][q] *= s0[q]; ev[px][gi][4 + q] *= s1[q]; }
+            }
+        }
+    }
+#pragma unroll
+    for (int px = 0; px < NPX; ++px) {
+        if (epix[px] >= p.npix) continue;
+#pragma unroll
+        for (int gi = 0; gi < NG; ++gi)
+            if (eco[gi] < p.cout) store8<DBG>(p, ev[px][gi], epix[px], eco[gi]);
+    }
+}
+
+// persistent grid: one workgroup per CU (every configuration needs > 80 KiB of LDS)
+static inline int dma_grid_limit() {
+    static const int ncu = [] {
+        int dev = 0, n = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+        return n;
+    }();
+    return ncu;
+}

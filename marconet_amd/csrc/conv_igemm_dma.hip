@@ -20,27 +20,7 @@
 //    tensor and channel offset are wave-uniform scalars advanced incrementally — no integer division in the loop.
 //  * the epilogue runs as whole-register-set passes behind wave-uniform branches (a per-element `switch (act)` compiled
 //    to ~1000 scalar branches / 100 KB of code and cost 10 us per tile).
-#include <cstdlib>
-#include "common.h"
-#include "conv_args.h"
-
-typedef __attribute__((address_space(3))) void lds_void;
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-
-__device__ __forceinline__ int swz_dma(int row, int chunk) { return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4); }
-
-#define VMCNT(n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
-
-// store 8 consecutive output channels co..co+7 of pixel `pix` (DBG: diagnostic variants, see launch_dma_id)
-template <int DBG>
-__device__ __forceinline__ void store8(const ConvArgs& p, const float* v, int pix, int co) {
-    if constexpr (DBG == 5) {           // DIAGNOSTIC: no stores (values kept live)
-        asm volatile("" :: "v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]), "v"(v[4]), "v"(v[5]), "v"(v[6]), "v"(v[7]));
-        return;
-    }
-    if constexpr (DBG == 4) pix &= 255;  // DIAGNOSTIC: every tile stores over tile 0 (L2-resident writes)
-    stg16(reinterpret_cast<f16*>(p.y) + (size_t)pix * p.cout + co, Vec<f16>::pack(v));
-}
+#include "conv_dma_common.h"
 
 // MF = 16: v_mfma_f32_16x16x32_f16 — production;
 // MF = 32: v_mfma_f32_32x32x16_f16 — experimental (half the matrix instructions per slab; not faster here: the kernel is
@@ -105,21 +85,11 @@ __global__ void __launch_bounds__(WC * WP * 64, WC * WP / 4) conv_dma_kernel(con
         nX0 = (int)(img0 * nimg);
         bX1 = (unsigned long long)(p.x1 ? reinterpret_cast<const char*>(p.x1) + (size_t)n_first * img1 : reinterpret_cast<const char*>(p.x0));
         nX1 = (int)(p.x1 ? img1 * nimg : 0);
-        // Weight rows are permuted on their way into LDS (free: the DMA source address is per lane) so that the MFMA
-        // fragments of a lane together hold 8 CONSECUTIVE output channels:
-        //   MF = 16: LDS row 64b + 16f + i holds channel 64b + 32(f/2) + 8(i/4) + 4(f%2) + i%4
-        //   MF = 32: LDS row 32b + i (D row i = 8q + 4h + e of lane-half h) holds channel 32b + 16h + 4q + e
+        // Weight rows are permuted on their way into LDS (free: the DMA source address is per lane), see dma_weight_channel
 #pragma unroll
         for (int j = 0; j < WJ; ++j) {
             const int row = (wave + NW * j) * 8 + rg;
-            int ch;
-            if constexpr (MF == 16) {
-                const int f = (row >> 4) & 3, i = row & 15;
-                ch = (row & ~63) + ((f >> 1) << 5) + ((i >> 2) << 3) + ((f & 1) << 2) + (i & 3);
-            } else {
-                const int i = row & 31;
-                ch = (row & ~31) + (((i >> 2) & 1) << 4) + ((i >> 3) << 2) + (i & 3);
-            }
+            const int ch = dma_weight_channel<MF>(row);
             const int lc = pc ^ ((row >> 1) & 7);
             woff[j] = (co0 + ch < p.cout) ? (unsigned)(ch * p.K * 2 + lc * 16) : OOB;
         }
@@ -303,90 +273,9 @@ __global__ void __launch_bounds__(WC * WP * 64, WC * WP / 4) conv_dma_kernel(con
         }
         if constexpr (DBG >= 3) { stamp[2] = wall_clock64(); cyc = (long long)__builtin_readcyclecounter() - cyc; }
 
-        // ---- epilogue (identical math to conv_igemm.hip).  Every lane owns NG groups of 8 consecutive output channels for
-        // each of its NPX pixels; whole-register-set passes, each behind ONE wave-uniform branch, then 16-byte stores.
         int co0, pix0;
         tile_coords(c_v, co0, pix0);
-        constexpr int NPX = MF == 16 ? FP : FP / 2;          // pixels per lane
-        constexpr int NG = MF == 16 ? FC / 2 : FC;           // 8-channel groups per pixel per lane
-        float ev[NPX][NG][8];
-        int epix[NPX], eco[NG];
-#pragma unroll
-        for (int gi = 0; gi < NG; ++gi)
-            eco[gi] = MF == 16 ? co0 + wc * (BC / WC) + gi * 32 + g * 8
-                               : co0 + wc * (BC / WC) + (gi >> 1) * 32 + (lane >> 5) * 16 + (gi & 1) * 8;
-#pragma unroll
-        for (int px = 0; px < NPX; ++px) {
-            epix[px] = MF == 16 ? pix0 + wp * (BP / WP) + px * 16 + l16 : pix0 + wp * (BP / WP) + px * 32 + (lane & 31);
-#pragma unroll
-            for (int gi = 0; gi < NG; ++gi)
-#pragma unroll
-                for (int q = 0; q < 8; ++q) {
-                    if constexpr (MF == 16) ev[px][gi][q] = acc[2 * gi + (q >> 2)][px][q & 3];
-                    else ev[px][gi][q] = acc32[gi >> 1][px][(gi & 1) * 8 + q];
-                }
-        }
-        const int last_pix = p.npix - 1;
-        if (p.out_scale) {
-#pragma unroll
-            for (int px = 0; px < NPX; ++px) {
-                const float* sp = p.out_scale + (size_t)(min(epix[px], last_pix) / p.howo) * p.cout;
-#pragma unroll
-                for (int gi = 0; gi < NG; ++gi) {
-                    if (eco[gi] >= p.cout) continue;
-                    const f32x4 s0 = *reinterpret_cast<const f32x4*>(sp + eco[gi]), s1 = *reinterpret_cast<const f32x4*>(sp + eco[gi] + 4);
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) { ev[px][gi][q] *= s0[q]; ev[px][gi][4 + q] *= s1[q]; }
-                }
-            }
-        }
-        if (p.bias) {
-#pragma unroll
-            for (int gi = 0; gi < NG; ++gi) {
-                if (eco[gi] >= p.cout) continue;
-                const f32x4 b0 = *reinterpret_cast<const f32x4*>(p.bias + eco[gi]), b1 = *reinterpret_cast<const f32x4*>(p.bias + eco[gi] + 4);
-#pragma unroll
-                for (int px = 0; px < NPX; ++px)
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) { ev[px][gi][q] += b0[q]; ev[px][gi][4 + q] += b1[q]; }
-            }
-        }
-        if (p.res) {
-            const f16* rs = reinterpret_cast<const f16*>(p.res);
-#pragma unroll
-            for (int px = 0; px < NPX; ++px) {
-                if (epix[px] >= p.npix) continue;
-                const int rpix = p.res_mod > 0 ? epix[px] % p.res_mod : epix[px];
-#pragma unroll
-                for (int gi = 0; gi < NG; ++gi) {
-                    if (eco[gi] >= p.cout) continue;
-                    const f16x8 r8 = bitcast<f16x8>(ldg16(rs + (size_t)rpix * p.cout + eco[gi]));
-#pragma unroll
-                    for (int q = 0; q < 8; ++q) ev[px][gi][q] += (float)r8[q];
-                }
-            }
-        }
-        act_apply_vec<NPX * NG * 8, true>(&ev[0][0][0], p.act);     // this path only takes the cheap (branch-free) activations
-        if (p.post_scale) {
-#pragma unroll
-            for (int px = 0; px < NPX; ++px) {
-                const float* sp = p.post_scale + (size_t)(min(epix[px], last_pix) / p.howo) * p.cout;
-#pragma unroll
-                for (int gi = 0; gi < NG; ++gi) {
-                    if (eco[gi] >= p.cout) continue;
-                    const f32x4 s0 = *reinterpret_cast<const f32x4*>(sp + eco[gi]), s1 = *reinterpret_cast<const f32x4*>(sp + eco[gi] + 4);
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) { ev[px][gi][q] *= s0[q]; ev[px][gi][4 + q] *= s1[q]; }
-                }
-            }
-        }
-#pragma unroll
-        for (int px = 0; px < NPX; ++px) {
-            if (epix[px] >= p.npix) continue;
-#pragma unroll
-            for (int gi = 0; gi < NG; ++gi)
-                if (eco[gi] < p.cout) store8<DBG>(p, ev[px][gi], epix[px], eco[gi]);
-        }
+        dma_epilogue<BC, BP, WC, WP, MF, DBG, FC, FP>(p, acc, acc32, co0, pix0, wc, wp, lane);
         drain = true;
 
         if constexpr (DBG >= 3) {       // DIAGNOSTIC: overwrite part of the output with this tile's time stamps
@@ -402,15 +291,6 @@ __global__ void __launch_bounds__(WC * WP * 64, WC * WP / 4) conv_dma_kernel(con
             }
         }
     }
-}
-
-static int dma_grid_limit() {            // persistent grid: one workgroup per CU (every configuration needs > 80 KiB of LDS)
-    static const int ncu = [] {
-        int dev = 0, n = 0;
-        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
-        return n;
-    }();
-    return ncu;
 }
 
 template <int BC, int BP, int WC, int WP, int STAGES, int MF = 16, int DBG = 0>

@@ -413,6 +413,57 @@ def test_conv_lds_dma_every_tile_config(cfg, shape):
         assert torch.equal(y_cfg, y_auto), "tile configuration %d differs from the auto-picked configuration" % cfg
 
 
+STRIP_CASES = [  # n, h, w, cin, cout  (all >= 65536 output pixels; 3x3 / stride 1 / pad 1)
+    (70, 32, 32, 64, 256),        # narrow maps: a 256-pixel tile = 8 image rows, strip 8 x 34
+    (256, 16, 16, 128, 320),      # W = 16: one image per tile, strip 16 x 18; cout tail (320 = 256 + 64)
+    (2, 64, 512, 64, 256),        # wide maps: a tile = half an image row, strip 258 (left / right neighbours or zero)
+    (17, 64, 64, 192, 256),       # 4 rows per tile, 3 channel slices
+    (64, 32, 32, 128, 64),        # 64x512 tile: 16 image rows, strip 16 x 34
+    (1, 32, 2048, 64, 64),        # 64x512 tile on a wide map
+    (5, 128, 128, 64, 96),        # 4 rows of 128 per 512-pixel tile, cout tail
+]
+
+
+@pytest.mark.parametrize("case", STRIP_CASES)
+def test_conv_strip_kernel(case):
+    """the 3x3 strip kernel (one activation strip per filter row, three taps read it at offsets 0/1/2) is bit-identical to the per-tap LDS-DMA kernel (same k order, same MFMA) with ragged valid
+    widths, residual, demodulation scale, bias and activation in the epilogue."""
+    ops = _ops()
+    from marconet_amd import _lib
+    import ctypes
+    dtype = torch.float16
+    n, h, w, cin, cout = case
+    g = torch.Generator().manual_seed(91)
+    x = (torch.rand((n, h, w, cin), generator=g) - 0.5).to(dtype).to(DEV)
+    wt = ((torch.rand((cout, 3, 3, cin), generator=g) - 0.5) * (2.0 / math.sqrt(9 * cin))).to(dtype).to(DEV)
+    bias = (torch.rand((cout,), generator=g) - 0.5).to(DEV)
+    osc = (torch.rand((n, cout), generator=g) + 0.5).to(DEV)
+    res = (torch.rand((n, h, w, cout), generator=g) - 0.5).to(dtype).to(DEV)
+    vw = torch.tensor([w - (i % 5) * 3 for i in range(n)], dtype=torch.int32, device=DEV)
+    kw = dict(valid_w=vw, out_scale=osc, bias=bias, residual=res, act=ops.ACT_LRELU)
+    strip = _lib.ALGO_STRIP_CFG0 + (0 if cout >= 256 else 1)
+    y_auto = ops.conv2d(x, wt, cout, 3, 3, (1, 1), (1, 1), algo=strip, **kw)
+    if cout < 128:      # AUTO takes the strip kernel for the 64x512 tile (the 256x256 form is by explicit request only)
+        ops.stats.reset(); ops.stats.enabled = ops.stats.timing = True
+        y_def = ops.conv2d(x, wt, cout, 3, 3, (1, 1), (1, 1), algo=0, **kw)
+        ops.stats.enabled = ops.stats.timing = False
+        assert ops.stats.events[-1][4] == strip and torch.equal(y_def, y_auto)
+    y_tap = ops.conv2d(x, wt, cout, 3, 3, (1, 1), (1, 1), algo=_lib.ALGO_LDS_DMA, **kw)
+    y_one = ops.conv2d(x, wt, cout, 3, 3, (1, 1), (1, 1), algo=strip | _lib.ALGO_FLAG_ONE_TILE, **kw)
+    torch.cuda.synchronize()
+    assert torch.equal(y_auto, y_tap), "strip kernel differs from the per-tap LDS-DMA kernel"
+    assert torch.equal(y_auto, y_one), "persistent and one-tile-per-workgroup launches differ"
+    # and against the fp32 reference on a slice of the batch
+    k = min(n, 2)
+    xs = x[:k].float().cpu().permute(0, 3, 1, 2).clone()
+    for i in range(k):
+        xs[i, :, :, int(vw[i]):] = 0
+    ref = F.conv2d(xs, wt.float().cpu().permute(0, 3, 1, 2), padding=1) * osc[:k].cpu()[:, :, None, None] + bias.cpu()[None, :, None, None] \
+        + res[:k].float().cpu().permute(0, 3, 1, 2)
+    ref = F.leaky_relu(ref, 0.2)
+    _check("conv strip %s" % (case,), y_auto[:k].float().cpu().permute(0, 3, 1, 2), ref, dtype, extra=2.0)
+
+
 def test_conv_lds_dma_eligibility():
     ops = _ops()
     from marconet_amd._lib import MarconetHipError
