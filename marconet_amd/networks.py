@@ -182,13 +182,24 @@ class TextGenerator(nn.Module):
         pk["rgb1"] = torgb(self.to_rgb1)
         pk["convs"] = [styled(c) for c in self.convs]
         pk["rgbs"] = [torgb(t) for t in self.to_rgbs]
+        # all 17 modulation EqualLinears read the same latent (:141 repeats one w for every layer): one GEMM
+        # [N,512] x [512, sum(Cin)] instead of 17 latency-bound launches; layer i takes columns mod_off[i] : +cin
+        layers = [pk["conv1"], pk["rgb1"]] + pk["convs"] + pk["rgbs"]
+        off = 0
+        for L in layers:
+            L["mod_off"] = off
+            off += L["cin"]
+        pk["mod_all_w"] = torch.cat([L["mod_w"] for L in layers], dim=0).contiguous()
+        pk["mod_all_b"] = torch.cat([L["mod_b"] for L in layers], dim=0).contiguous()
+        pk["mod_total"] = off
         return pk
 
     # ------------------------------------------------------------------ forward pieces
     @staticmethod
-    def _style(L, latent):
-        """modulation EqualLinear (:283) and the demodulation table rsqrt(Σ (scale·W·s)² + 1e-8) (:286)"""
-        s = ops.linear(latent, L["mod_w"], L["cin"], bias=L["mod_b"])
+    def _style(L, S):
+        """this layer's slice of the batched modulation EqualLinear (:283) and its demodulation table
+        rsqrt(Σ (scale·W·s)² + 1e-8) (:286)"""
+        s = S[:, L["mod_off"]:L["mod_off"] + L["cin"]].contiguous()
         return s, ops.demod(s, L["wsq_t"])
 
     @staticmethod
@@ -200,8 +211,8 @@ class TextGenerator(nn.Module):
                           out_scale=d, bias=L["bias"], act=ops.ACT_LRELU_SQRT2, post_scale=post)
 
     @staticmethod
-    def _to_rgb(L, x, latent, skip):
-        s = ops.linear(latent, L["mod_w"], L["cin"], bias=L["mod_b"])
+    def _to_rgb(L, x, S, skip):
+        s = S[:, L["mod_off"]:L["mod_off"] + L["cin"]].contiguous()
         if skip is not None:
             skip = ops.upsample2x(skip)                                        # :318-319
         return ops.conv2d(x, L["w"], RGB_PAD, in_scale=s, bias=L["bias"], residual=skip, act=ops.ACT_TANH)
@@ -216,6 +227,7 @@ class TextGenerator(nn.Module):
         for w, b in pk["mlp"]:
             lat = ops.linear(lat, w, self.style_dim, bias=b, act=ops.ACT_LRELU_SQRT2)
         x = ops.embed_gather(pk["emb"], labels, dtype, self.class_num)         # SelectText (:205-215)
+        lat = ops.linear(lat, pk["mod_all_w"], pk["mod_total"], bias=pk["mod_all_b"])    # every layer's modulation at once
         s, d = self._style(pk["conv1"], lat)
         x = self._styled(pk["conv1"], x, s, d, premodulated=False)
         skip = self._to_rgb(pk["rgb1"], x, lat, None) if need_image else None

@@ -53,6 +53,8 @@ class MarconetPipeline:
                 p32s.append(c)
             p64 = p64s[0] if len(p64s) == 1 else torch.cat(p64s)
             p32 = p32s[0] if len(p32s) == 1 else torch.cat(p32s)
+            sr_dtype = torch_dtype(self.sr.precision)                 # the three nets may run in different precision modes
+            p64, p32 = ops.convert(p64, sr_dtype), ops.convert(p32, sr_dtype)
         else:
             p64 = p32 = None
         y = self.sr.forward_packed(lq, p64, p32, counts, counts, locs)   # test_sr.py:197
@@ -200,3 +202,37 @@ def all_gather_outputs(local, total, group=None):
     if all(b - a == mx for a, b in sizes):
         return out
     return torch.cat([out[r * mx: r * mx + (b - a)] for r, (a, b) in enumerate(sizes)])
+
+
+class OverlappedGather:
+    """The all-gather of step i runs (on the collective backend's own stream) while step i+1 computes: ``submit`` enqueues
+    it asynchronously into one of two rotating output buffers and returns the gathered result of the PREVIOUS submit
+    (None the first time); ``flush`` waits for the last one.  Even shards only (the data-parallel bench)."""
+
+    def __init__(self, group=None):
+        self.group = group
+        self._bufs = [None, None]
+        self._pending = None          # (work handle, buffer, source tensor kept alive)
+        self._i = 0
+
+    def submit(self, local):
+        import torch.distributed as dist
+        world = dist.get_world_size(self.group)
+        done = self.flush()
+        shape = (world * local.shape[0],) + tuple(local.shape[1:])
+        buf = self._bufs[self._i]
+        if buf is None or buf.shape != shape or buf.dtype != local.dtype or buf.device != local.device:
+            buf = self._bufs[self._i] = torch.empty(shape, dtype=local.dtype, device=local.device)
+        src = local.contiguous()
+        work = dist.all_gather_into_tensor(buf, src, group=self.group, async_op=True)
+        self._pending = (work, buf, src)
+        self._i ^= 1
+        return done
+
+    def flush(self):
+        if self._pending is None:
+            return None
+        work, buf, _ = self._pending
+        work.wait()
+        self._pending = None
+        return buf

@@ -37,7 +37,14 @@ def _worker(rank, world, port, total, out_q):
         local = torch.stack([_fake_sr(i) for i in range(a, b)]) if b > a else torch.zeros((0, 3, 8, 32))
         full = all_gather_outputs(local, total)
         want = torch.stack([_fake_sr(i) for i in range(total)])
-        out_q.put((rank, tuple(full.shape), bool(torch.equal(full, want)), (a, b)))
+        ok = bool(torch.equal(full, want))
+        if total % world == 0:        # the overlapped (asynchronous, double-buffered) form used by bench.py --gpus N
+            from marconet_amd.pipeline import OverlappedGather
+            og = OverlappedGather()
+            assert og.submit(local) is None
+            prev = og.submit(local * 2)                       # returns step 0's result while step 1's gather is in flight
+            ok = ok and bool(torch.equal(prev, want)) and bool(torch.equal(og.flush(), want * 2)) and og.flush() is None
+        out_q.put((rank, tuple(full.shape), ok, (a, b)))
     finally:
         dist.destroy_process_group()
 
