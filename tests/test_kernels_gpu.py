@@ -464,6 +464,56 @@ def test_conv_strip_kernel(case):
     _check("conv strip %s" % (case,), y_auto[:k].float().cpu().permute(0, 3, 1, 2), ref, dtype, extra=2.0)
 
 
+def _fuzz_cases():
+    import random
+    rng = random.Random(20260926)
+    cases = []
+    for i in range(24):
+        k = rng.choice([1, 3, 3, 3])
+        cin = 64 * rng.randint(1, 4)
+        c1 = rng.choice([0, 0, 64]) if cin > 64 else 0
+        cout = rng.choice([64, 72, 128, 136, 256, 264, 320, 512])
+        stride = rng.choice([(1, 1), (1, 1), (1, 1), (2, 1), (2, 2)]) if k == 3 else (1, 1)
+        big = i % 3 == 0                                   # every third case: > 256 pixel tiles → persistent grid makes several passes
+        h, w = (rng.randint(100, 180), rng.randint(300, 420)) if big else (rng.randint(3, 40), rng.randint(8, 70))
+        n = rng.randint(1, 3) if big else rng.randint(1, 9)
+        cases.append((n, h, w, cin - c1, c1, cout, k, stride))
+    cases += [(4, 64, 64, 64, 0, 256, 3, (1, 1)), (2, 128, 128, 128, 0, 64, 3, (1, 1)), (300, 16, 16, 64, 0, 512, 3, (1, 1))]   # strip-eligible
+    return cases
+
+
+@pytest.mark.parametrize("case", _fuzz_cases())
+def test_conv_f16_fuzz_all_paths_agree(case):
+    """seeded random shapes (pixel / cout tails, concat, strides, 1x1, ragged widths, multi-pass persistent grids, tilesC > 1):
+    whatever AUTO picks (per-tap LDS-DMA, strip, register-staged) == the pinned per-tap kernel bit for bit, and both agree
+    with the register-staged kernel to f16 rounding and with F.conv2d on a slice."""
+    ops = _ops()
+    from marconet_amd import _lib
+    dtype = torch.float16
+    n, h, w, c0, c1, cout, k, stride = case
+    pad = k // 2
+    g = torch.Generator().manual_seed(hash(case) & 0xffff)
+    x0 = (torch.rand((n, h, w, c0), generator=g) - 0.5).to(dtype).to(DEV)
+    x1 = (torch.rand((n, h, w, c1), generator=g) - 0.5).to(dtype).to(DEV) if c1 else None
+    wt = ((torch.rand((cout, k, k, c0 + c1), generator=g) - 0.5) * (2.0 / math.sqrt(k * k * (c0 + c1)))).to(dtype).to(DEV)
+    bias = (torch.rand((cout,), generator=g) - 0.5).to(DEV)
+    vw = torch.tensor([max(1, w - (i % 4) * 2) for i in range(n)], dtype=torch.int32, device=DEV)
+    kw = dict(x1=x1, valid_w=vw, bias=bias, act=ops.ACT_LRELU_SQRT2)
+    y_auto = ops.conv2d(x0, wt, cout, k, k, stride, (pad, pad), algo=0, **kw)
+    y_tap = ops.conv2d(x0, wt, cout, k, k, stride, (pad, pad), algo=_lib.ALGO_LDS_DMA, **kw)
+    y_one = ops.conv2d(x0, wt, cout, k, k, stride, (pad, pad), algo=_lib.ALGO_LDS_DMA | _lib.ALGO_FLAG_ONE_TILE, **kw)
+    y_reg = ops.conv2d(x0, wt, cout, k, k, stride, (pad, pad), algo=_lib.ALGO_REG_STAGED, **kw)
+    torch.cuda.synchronize()
+    assert torch.equal(y_auto, y_tap) and torch.equal(y_tap, y_one)
+    d = (y_tap.float() - y_reg.float()).abs()
+    assert float(d.max()) <= 2.0 ** -9 * float(y_reg.float().abs().max())
+    xs = torch.cat([x0[:1], x1[:1]], dim=3) if c1 else x0[:1]
+    xs = xs.float().cpu().permute(0, 3, 1, 2).clone()
+    xs[0, :, :, int(vw[0]):] = 0
+    ref = F.leaky_relu(F.conv2d(xs, wt.float().cpu().permute(0, 3, 1, 2), stride=stride, padding=pad) + bias.cpu()[None, :, None, None], 0.2) * 2 ** 0.5
+    _check("conv fuzz %s" % (case,), y_auto[:1].float().cpu().permute(0, 3, 1, 2), ref, dtype, extra=2.0)
+
+
 def test_conv_lds_dma_eligibility():
     ops = _ops()
     from marconet_amd._lib import MarconetHipError
