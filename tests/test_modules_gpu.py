@@ -318,3 +318,29 @@ def test_forward_blind_runs_end_to_end(nets):
     lq = synth.make_lq(81, 2, [400, 512]).to(DEV)
     sr, labels, locs = pipe.forward_blind(lq)
     assert sr.shape == (2, 3, 128, 2048) and torch.isfinite(sr).all() and len(labels) == 2 and locs.shape == (2, 32)
+
+
+def test_full_size_batch_properties_fp16(nets):
+    """BASELINE configs[1] at full size (64 strips x 16 glyphs, fp16 throughput mode), checked through size-independent
+    properties instead of the (hours-long) CPU oracle: the batch equals its two halves run separately bit for bit (what
+    makes an N-GPU data-parallel run equal the 1-GPU run), images are processed independently (a permuted
+    batch gives permuted outputs), and the output is finite and tanh-bounded."""
+    from marconet_amd.pipeline import MarconetPipeline
+    B, n = 64, 16
+    lq = synth.make_lq(91, B, [512] * B).to(DEV)
+    labels = [synth.make_labels(100 + b, n).to(DEV) for b in range(B)]
+    locs = synth.make_locs([n] * B, [512] * B).to(DEV)
+    pipe = MarconetPipeline(*nets, precision="fp16")
+    try:
+        full = pipe.forward_batch(lq, labels, locs)
+        assert full.shape == (B, 3, 128, 2048) and torch.isfinite(full).all() and float(full.abs().max()) <= 1.0
+        h = B // 2
+        lo = pipe.forward_batch(lq[:h].contiguous(), labels[:h], locs[:h].contiguous())
+        hi = pipe.forward_batch(lq[h:].contiguous(), labels[h:], locs[h:].contiguous())
+        assert torch.equal(full[:h], lo) and torch.equal(full[h:], hi)
+        perm = torch.randperm(B, generator=torch.Generator().manual_seed(7)).tolist()
+        pt = torch.tensor(perm, device=DEV)
+        shuffled = pipe.forward_batch(lq.index_select(0, pt), [labels[i] for i in perm], locs.index_select(0, pt))
+        assert torch.equal(shuffled, full.index_select(0, pt))
+    finally:
+        pipe.set_precision("fp32")
