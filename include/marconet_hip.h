@@ -221,6 +221,12 @@ int mnet_convert(const void* src, int32_t src_dtype, void* dst, int32_t dst_dtyp
 int mnet_fused_bias_act(const float* x, const float* bias, float* y, int64_t total, int32_t C, int32_t inner,
                         float negative_slope, float scale, void* stream);
 
+/* K19, the script's output post-processing (test_sr.py:198-200): sr*0.5+0.5 → HWC → RGB→BGR → clip(0,1)*255.
+ * src NHWC [npix][c_ld] (RGB in channels 0..2, f32 or f16); dst [npix][3] BGR as float32 (dst_u8 == 0: exactly what the
+ * script hands to cv2.imwrite) or uint8 (dst_u8 != 0: cv2's float→uchar conversion, round half to even) — 4x fewer bytes
+ * for the device→host copy and the multi-GPU all-gather (SURVEY.md §8f NEXT-1) */
+int mnet_sr_postprocess(const void* src, int32_t src_dtype, void* dst, int32_t dst_u8, int64_t npix, int32_t c_ld, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

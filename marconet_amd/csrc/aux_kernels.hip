@@ -577,3 +577,38 @@ extern "C" int mnet_affine_act_nhwc(const void* x, void* y, int32_t dtype, int32
     MNET_LAUNCH_CHECK("affine_act");
     return MNET_OK;
 }
+
+// ============================================================================ K19: SR output post-processing (test_sr.py:198-200)
+//   sr*0.5 + 0.5 → HWC → RGB→BGR flip → clip(0,1) * 255     as float32 (what the script hands to cv2) or as uint8 with
+//   cv2.imwrite's float→uchar conversion (round half to even, saturate).  src NHWC [n, hw, c_ld] (RGB in channels 0..2).
+template <typename T, typename O>
+__global__ void __launch_bounds__(256) sr_postprocess_kernel(const T* __restrict__ src, O* __restrict__ dst, long long npix, int c_ld) {
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < npix; i += (long long)gridDim.x * 256) {
+        const T* s = src + (size_t)i * c_ld;
+        O* d = dst + (size_t)i * 3;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            float v = __fadd_rn(__fmul_rn((float)s[c], 0.5f), 0.5f);
+            v = fminf(fmaxf(v, 0.f), 1.f) * 255.0f;
+            if constexpr (sizeof(O) == 1) d[2 - c] = (O)__float2int_rn(v);       // 0..255 after the clip
+            else d[2 - c] = (O)v;
+        }
+    }
+}
+
+extern "C" int mnet_sr_postprocess(const void* src, int32_t src_dtype, void* dst, int32_t dst_u8, int64_t npix, int32_t c_ld,
+                                   void* stream) {
+    MNET_CHECK_ARG(src && dst && npix > 0 && c_ld >= 3, "sr_postprocess: bad args");
+    MNET_CHECK_ARG(src_dtype == MNET_F32 || src_dtype == MNET_F16, "sr_postprocess: bad dtype");
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    const int grid = (int)((npix + 255) / 256 < 65536 ? (npix + 255) / 256 : 65536);
+    if (src_dtype == MNET_F16) {
+        if (dst_u8) hipLaunchKernelGGL((sr_postprocess_kernel<f16, unsigned char>), dim3(grid), dim3(256), 0, st, (const f16*)src, (unsigned char*)dst, (long long)npix, c_ld);
+        else hipLaunchKernelGGL((sr_postprocess_kernel<f16, float>), dim3(grid), dim3(256), 0, st, (const f16*)src, (float*)dst, (long long)npix, c_ld);
+    } else {
+        if (dst_u8) hipLaunchKernelGGL((sr_postprocess_kernel<float, unsigned char>), dim3(grid), dim3(256), 0, st, (const float*)src, (unsigned char*)dst, (long long)npix, c_ld);
+        else hipLaunchKernelGGL((sr_postprocess_kernel<float, float>), dim3(grid), dim3(256), 0, st, (const float*)src, (float*)dst, (long long)npix, c_ld);
+    }
+    MNET_LAUNCH_CHECK("sr_postprocess");
+    return MNET_OK;
+}

@@ -13,7 +13,7 @@ from ._lib import (ACT_GELU, ACT_LRELU, ACT_LRELU_SQRT2, ACT_NONE, ACT_RELU, ACT
 
 __all__ = ["conv2d", "linear", "nchw_to_nhwc", "nhwc_to_nchw", "upsample2x", "affine_act", "groupnorm_affine",
            "adain_crop_concat", "glyph_scatter_affine", "layernorm", "token_mix", "attention", "pixelnorm",
-           "embed_gather", "demod", "argmax_rows", "convert", "fused_bias_act", "stats",
+           "embed_gather", "demod", "argmax_rows", "convert", "fused_bias_act", "sr_postprocess", "stats",
            "ACT_NONE", "ACT_RELU", "ACT_LRELU", "ACT_LRELU_SQRT2", "ACT_TANH", "ACT_GELU", "ACT_SIGMOID"]
 
 
@@ -299,3 +299,15 @@ def fused_bias_act(x, bias, negative_slope=0.2, scale=2 ** 0.5):
     _lib.check(lib.mnet_fused_bias_act(_p(x), _p(bias), _p(y), x.numel(), C, inner, negative_slope, scale, _stream()),
                "mnet_fused_bias_act")
     return y
+
+
+def sr_postprocess(y_nhwc, u8=True):
+    """test_sr.py:198-200 on the NHWC SR tensor [B,H,W,c_ld] (RGB in channels 0..2) → [B,H,W,3] BGR, uint8 (cv2.imwrite's
+    rounding) or float32 (the array the script passes to cv2)."""
+    lib = _lib.load()
+    _need_cuda(y_nhwc)
+    b, h, w, c_ld = y_nhwc.shape
+    out = torch.empty((b, h, w, 3), dtype=torch.uint8 if u8 else torch.float32, device=y_nhwc.device)
+    _lib.check(lib.mnet_sr_postprocess(_p(y_nhwc), _dt(y_nhwc), _p(out), 1 if u8 else 0, b * h * w, c_ld, _stream()),
+               "mnet_sr_postprocess")
+    return out

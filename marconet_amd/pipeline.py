@@ -30,9 +30,11 @@ class MarconetPipeline:
         return self
 
     @torch.no_grad()
-    def forward_batch(self, lq, labels, locs, return_nhwc=False):
+    def forward_batch(self, lq, labels, locs, return_nhwc=False, output="nchw_f32"):
         """lq [B,3,32,512] fp32 (device); labels: list of B int64 [n_b,1] tensors; locs [B, ≥2·max n_b] fp32.
-        → SR [B,3,128,2048] fp32 NCHW (or NHWC [B,128,2048,8] in the compute dtype if return_nhwc)."""
+        → SR [B,3,128,2048] fp32 NCHW (the reference's return), or NHWC [B,128,2048,8] in the compute dtype if return_nhwc,
+        or — output="u8_bgr" — the script's post-processed image [B,128,2048,3] uint8 BGR (test_sr.py:198-200; 4x fewer bytes
+        to copy to the host or to all-gather)."""
         dev = lq.device
         B = lq.shape[0]
         counts = [int(l.shape[0]) for l in labels]
@@ -58,6 +60,8 @@ class MarconetPipeline:
         else:
             p64 = p32 = None
         y = self.sr.forward_packed(lq, p64, p32, counts, counts, locs)   # test_sr.py:197
+        if output == "u8_bgr":                                           # test_sr.py:198-200 fused: [B,128,2048,3] uint8
+            return ops.sr_postprocess(y, u8=True)
         return y if return_nhwc else ops.nhwc_to_nchw(y, c=3)
 
 

@@ -4,6 +4,7 @@ order only); f16 kernels are fed fp16-rounded inputs, the reference is computed 
 values, so the only differences are accumulation order and the final fp16 rounding (2e-3 relative)."""
 import math
 
+import numpy as np
 import pytest
 import torch
 import torch.nn.functional as F
@@ -521,3 +522,17 @@ def test_conv_lds_dma_eligibility():
     w = torch.zeros(64, 3, 3, 32, dtype=torch.float16, device=DEV)
     with pytest.raises(MarconetHipError):
         ops.conv2d(x, w, 64, 3, 3, (1, 1), (1, 1), algo=2)        # cin % 64 != 0
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float16])
+def test_sr_postprocess_matches_script(dtype):
+    """K19 (test_sr.py:198-200): float output == the script's torch/numpy sequence bit for bit; uint8 == its rint + saturate"""
+    ops = _ops()
+    g = torch.Generator().manual_seed(11)
+    y = ((torch.rand((3, 16, 40, 8), generator=g) - 0.5) * 3.0).to(dtype)          # beyond [-1,1] to exercise the clip
+    sr = y[..., :3].float().permute(0, 3, 1, 2)                                     # what modelSR would return (NCHW)
+    want = np.clip((sr * 0.5 + 0.5).permute(0, 2, 3, 1).flip(3).numpy(), 0, 1) * 255.0
+    got_f = ops.sr_postprocess(y.to(DEV), u8=False).cpu().numpy()
+    got_u = ops.sr_postprocess(y.to(DEV), u8=True).cpu().numpy()
+    assert np.array_equal(got_f, want.astype(np.float32))
+    assert np.array_equal(got_u, np.rint(want).astype(np.uint8))
