@@ -112,6 +112,7 @@ def main():
     # ---- secondary figure (reported separately, never the headline): the same step without the generator's 128-px
     # structure image, which only feeds test_sr.py's saved visualisation (SURVEY.md §7 "hard parts", last item)
     secondary = None
+    prec16 = a.precision == "fp16"
     if not a.no_secondary:
         pipe.need_prior_image = False
         step()
@@ -128,6 +129,18 @@ def main():
             dt2 = float(t.item())
         secondary = {"images_per_s_without_prior_image": round(B * world * a.steps / dt2, 3), "ms_per_step": round(dt2 / a.steps * 1e3, 3),
                      "note": "opt-in MarconetPipeline(need_prior_image=False): TSPGAN stops at the 64-px level; SR output identical"}
+        if world == 1 and prec16:
+            # the fp32 parity mode (<= 1e-3 vs the reference, bit-exact indices: see "parity" below) on a 16-image slice
+            kb = min(B, 16)
+            pipe.set_precision("fp32")
+            pipe.forward_batch(lq[:kb], labels[:kb], locs[:kb])
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            pipe.forward_batch(lq[:kb], labels[:kb], locs[:kb])
+            torch.cuda.synchronize()
+            secondary["fp32_parity_mode_images_per_s"] = round(kb / (time.perf_counter() - t0), 3)
+            secondary["fp32_parity_mode_batch"] = kb
+            pipe.set_precision(a.precision)
 
     # ---- roofline of the dominant kernel, from the live HIP events of the timed steps (events are recorded on the
     # launch stream around every conv launch; the kernel each launch resolved to comes from mnet_conv2d_plan)
