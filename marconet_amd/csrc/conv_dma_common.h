@@ -134,6 +134,8 @@ static inline int dma_grid_limit() {
     static const int ncu = [] {
         int dev = 0, n = 0;
         if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+        const char* e = getenv("MNET_DMA_GRID");        // experiment knob: persistent workgroups (= CUs used) of the LDS-DMA kernels
+        if (e && atoi(e) > 0 && atoi(e) < n) n = atoi(e);
         return n;
     }();
     return ncu;

@@ -31,7 +31,8 @@ class MarconetPipeline:
 
     @torch.no_grad()
     def forward_batch(self, lq, labels, locs, return_nhwc=False, output="nchw_f32"):
-        """lq [B,3,32,512] fp32 (device); labels: list of B int64 [n_b,1] tensors; locs [B, ≥2·max n_b] fp32.
+        """lq [B,3,32,512] fp32 (device); labels: list of B int64 [n_b,1] tensors; locs [B, ≥2·max n_b] fp32 — labels and
+        locs on the device or (preferably: no synchronisation then) on the host.
         → SR [B,3,128,2048] fp32 NCHW (the reference's return), or NHWC [B,128,2048,8] in the compute dtype if return_nhwc,
         or — output="u8_bgr" — the script's post-processed image [B,128,2048,3] uint8 BGR (test_sr.py:198-200; 4x fewer bytes
         to copy to the host or to all-gather)."""
@@ -42,10 +43,13 @@ class MarconetPipeline:
         tg = self.gan.TextGenerator
         tg.precision = self.precision
         if sum(counts):
-            lab = torch.cat([l.reshape(-1, 1) for l in labels if l.shape[0]], dim=0).to(dev).long().contiguous()
+            lab = torch.cat([l.reshape(-1, 1) for l in labels if l.shape[0]], dim=0).long()
+            # labels / locs held on the HOST (where the OCR / detector front-end leaves them, test_sr.py:121-149) cost no
+            # device→host synchronisation: the whole forward is then enqueued without the host ever waiting for the GPU
             if int(lab.min()) < 0 or int(lab.max()) >= tg.class_num:
                 raise RuntimeError("label index out of range [0,%d)" % tg.class_num)
-            img_of = torch.repeat_interleave(torch.arange(B, device=dev), torch.tensor(counts, device=dev))
+            lab = lab.to(dev).contiguous()
+            img_of = torch.repeat_interleave(torch.arange(B), torch.tensor(counts)).to(dev)
             styles = w.index_select(0, img_of).contiguous()           # w0.repeat(n,1) per image (test_sr.py:183)
             p64s, p32s = [], []
             for s in range(0, lab.shape[0], self.glyph_chunk):        # bounded working set for huge batches
