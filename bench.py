@@ -71,8 +71,10 @@ def main():
     B, n = a.batch, a.glyphs
     widths = [512] * B
     lq = synthetic.make_lq(1234 + rank, B, widths).to(dev)
-    labels = [synthetic.make_labels(1234 + 1000 * rank + b, n).to(dev) for b in range(B)]
-    locs = synthetic.make_locs([n] * B, widths).to(dev)
+    # labels and glyph locations stay on the HOST, where the OCR / detector front-end leaves them (test_sr.py:121-149):
+    # the forward then needs no device→host synchronisation at all
+    labels = [synthetic.make_labels(1234 + 1000 * rank + b, n) for b in range(B)]
+    locs = synthetic.make_locs([n] * B, widths)
 
     gather = OverlappedGather() if world > 1 and not a.no_gather else None
 
@@ -219,8 +221,8 @@ def main():
             avail = os.cpu_count() or 1
         threads = max(1, min(avail, a.cpu_threads))
         torch.set_num_threads(threads)
-        lq_c, locs_c = lq[:k].cpu(), locs[:k].cpu()
-        lab_c = [l.cpu() for l in labels[:k]]
+        lq_c, locs_c = lq[:k].cpu(), locs[:k]
+        lab_c = labels[:k]
         O.end_to_end(sde, sdg, sds, lq_c[:1], [lab_c[0][:2]], locs_c[:1])          # warm-up (small)
         t0 = time.perf_counter()
         refs = [O.end_to_end(sde, sdg, sds, lq_c[i:i + 1], lab_c[i:i + 1], locs_c[i:i + 1]) for i in range(k)]  # batch 1, like test_sr.py:77

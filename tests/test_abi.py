@@ -124,3 +124,25 @@ def test_missing_library_fails_loudly():
             "try:\n    _lib.load()\nexcept ImportError as e:\n    print('LOUD', e)\n")
     out = subprocess.check_output([sys.executable, "-c", code], cwd=ROOT).decode()
     assert "LOUD" in out and "no CPU/eager fallback" in out
+
+
+def test_glyph_tables_vectorised_equals_scalar_window():
+    """the numpy-vectorised GlyphTables == the scalar window arithmetic (models/networks.py:425-441) for random locations,
+    ragged glyph counts (including zero) and both scales; out-of-map windows raise like the reference"""
+    import numpy as np
+    import pytest
+    from marconet_amd.glyphs import GlyphTables, window
+    rng = np.random.default_rng(7)
+    for _ in range(100):
+        B = int(rng.integers(1, 7))
+        counts = [int(rng.integers(0, 9)) for _ in range(B)]
+        W, half = ((512, 16), (1024, 32), (256, 16), (640, 32))[int(rng.integers(0, 4))]
+        locs = rng.random((B, 16)).astype(np.float32)
+        t = GlyphTables(locs, counts, W, half, "cpu")
+        exp = [(b,) + window(locs[b, 2 * c], W, half) for b, n in enumerate(counts) for c in range(n)]
+        assert list(zip(t.g_img.tolist(), t.g_x1.tolist(), t.g_w.tolist(), t.g_y1.tolist())) == exp
+        assert t.g_start.tolist() == [0] + list(np.cumsum(counts)) and t.G == sum(counts)
+    with pytest.raises(ValueError):
+        GlyphTables(np.array([[1.2, 0.0]], dtype=np.float32), [1], 512, 16, "cpu")      # centre beyond the map → empty window
+    with pytest.raises(IndexError):
+        GlyphTables(np.zeros((1, 4), dtype=np.float32), [3], 512, 16, "cpu")
