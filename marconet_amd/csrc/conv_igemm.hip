@@ -1,5 +1,8 @@
-// Implicit-GEMM convolution for gfx950 (MI355X, CDNA4) — the kernel that carries >95 % of the FLOPs of
-// the MARCONet forward.
+// Implicit-GEMM convolution for gfx950 (MI355X, CDNA4), the GENERAL (register-staged) kernel, and the dispatch of
+// mnet_conv2d_nhwc between it and the two LDS-DMA kernels (conv_igemm_dma.hip, conv_strip_dma.hip), which carry ~97 % of
+// the f16 FLOPs.  This kernel serves what those cannot: every fp32 launch (parity mode, the TextViT linears), input-side
+// transforms (style modulation of the first StyledConv / ToRGB, GroupNorm prologue), channel counts that are not multiples
+// of 64, cout < 64, tanh / GELU / sigmoid epilogues.
 //
 // GEMM view (computed transposed so that every lane ends up owning 4 *consecutive output channels*
 // of one pixel, which makes bias / demod / residual loads and the NHWC store 8- or 16-byte vector ops):
