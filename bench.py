@@ -58,6 +58,13 @@ def main():
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         dist.init_process_group("nccl", device_id=dev)
 
+    if world > 1:       # N ranks build the same seeded checkpoints on the host at the same time: do not oversubscribe its cores
+        try:
+            avail = len(os.sched_getaffinity(0))
+        except AttributeError:
+            avail = os.cpu_count() or 1
+        torch.set_num_threads(max(1, min(32, avail // world)))
+
     from marconet_amd import networks, ops, synthetic
     from marconet_amd.pipeline import MarconetPipeline, OverlappedGather
 
