@@ -315,6 +315,10 @@ static int launch_dtype(const ConvArgs& a, hipStream_t st) {
     // tile until the grid covers the CUs.  Every tile shape accumulates each output in the same k order, so
     // the choice never changes a result bit.
     const long long tilesP = (a.npix + 127) / 128;
+    static const int force = [] { const char* e = getenv("MNET_REG_TILE"); return e ? atoi(e) : 0; }();   // A/B knob: cout tile
+    if (force == 32 && a.cout >= 32) return launch_cfg<T, 32, 128, 1, 4>(a, st);
+    if (force == 64 && a.cout >= 64) return launch_cfg<T, 64, 128, 2, 2>(a, st);
+    if (force == 128 && a.cout >= 128) return launch_cfg<T, 128, 128, 2, 2>(a, st);
     if (a.cout >= 128 && tilesP * ((a.cout + 127) / 128) >= 512) return launch_cfg<T, 128, 128, 2, 2>(a, st);
     if (a.cout >= 64 && (a.cout < 128 || tilesP * ((a.cout + 63) / 64) >= 256)) return launch_cfg<T, 64, 128, 2, 2>(a, st);
     if (a.cout >= 128) return launch_cfg<T, 32, 128, 1, 4>(a, st);
