@@ -170,6 +170,15 @@ int mnet_adain_crop_concat(const void* prior, const void* feat, void* out, int32
                            int32_t S, int32_t C, int32_t feat_w, const int32_t* g_img,
                            const int32_t* g_x1, const int32_t* g_y1, const int32_t* g_w, void* stream);
 
+/* same, and additionally the GroupNorm (2C/32 groups of 32 channels, biased variance, eps) affine of the [G,S,S,2C] OUTPUT
+ * over each glyph's window — norm1 of conv_32_fuse / conv_64_fuse (networks.py:508) — in closed form from the AdaIN
+ * statistics the kernel has anyway (no further pass over the tensor):  scale[g,c] = rstd[g,grp]*gamma[c],
+ * shift[g,c] = beta[c] - mean[g,grp]*rstd[g,grp]*gamma[c];  gamma, beta fp32 [2C];  scale, shift fp32 [G][2C] */
+int mnet_adain_crop_concat_gn(const void* prior, const void* feat, void* out, int32_t dtype, int32_t G,
+                              int32_t S, int32_t C, int32_t feat_w, const int32_t* g_img,
+                              const int32_t* g_x1, const int32_t* g_y1, const int32_t* g_w,
+                              const float* gamma, const float* beta, float eps, float* scale, float* shift, void* stream);
+
 /* K13 ordered scatter:  out[b,y,x,:] = feat + (feat*scale[g,y,x-x1,:] + shift[g,y,x-x1,:]) for the LAST
  * glyph g of image b whose window covers x (later glyph overwrites earlier, :448,481); out = feat where
  * no window covers x.  Glyphs of image b are g_start[b] .. g_start[b+1]-1. */

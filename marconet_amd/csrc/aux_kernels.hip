@@ -246,7 +246,9 @@ template <typename T>
 __global__ void __launch_bounds__(256) adain_crop_kernel(const T* __restrict__ prior, const T* __restrict__ feat,
                                                          T* __restrict__ out, int S, int C, int FW,
                                                          const int* __restrict__ g_img, const int* __restrict__ g_x1,
-                                                         const int* __restrict__ g_y1, const int* __restrict__ g_w) {
+                                                         const int* __restrict__ g_y1, const int* __restrict__ g_w,
+                                                         const float* __restrict__ gn_gamma, const float* __restrict__ gn_beta,
+                                                         float gn_eps, float* __restrict__ gn_scale, float* __restrict__ gn_shift) {
     constexpr int N = Vec<T>::N;
     extern __shared__ __attribute__((aligned(16))) unsigned char dyn[];
     const int g = blockIdx.x, t = threadIdx.x;
@@ -255,6 +257,8 @@ __global__ void __launch_bounds__(256) adain_crop_kernel(const T* __restrict__ p
     const int img = g_img[g], x1 = g_x1[g], y1 = g_y1[g], gw = g_w[g];
     double* red = reinterpret_cast<double*>(dyn);                       // [256][N][4]  (only N*4 per thread)
     float* stat = reinterpret_cast<float*>(dyn + (size_t)256 * N * 4 * sizeof(double));   // [4][C]: pm, ps, fm, fs
+    double* gsum = reinterpret_cast<double*>(stat + 4 * C);              // [2][2C]: per output channel sum, sum of squares
+    float* gmr = reinterpret_cast<float*>(gsum + 4 * C);                 // [2C/32][2]: group mean, rstd
     const T* pbase = prior + (size_t)g * S * S * C + (size_t)ch * N;
     const T* fbase = feat + (size_t)img * S * FW * C + (size_t)ch * N;
     const int npx = S * gw;
@@ -293,8 +297,35 @@ __global__ void __launch_bounds__(256) adain_crop_kernel(const T* __restrict__ p
         if (pv < 0) pv = 0; if (fv < 0) fv = 0;
         stat[c] = (float)pm; stat[C + c] = sqrtf((float)pv + 1e-5f);
         stat[2 * C + c] = (float)fm; stat[3 * C + c] = sqrtf((float)fv + 1e-5f);
+        if (gn_scale) {     // per-channel sum / sum of squares of the [.., 2C] OUTPUT over the window, in closed form:
+                            // channel c (restyled prior) = (p - pm)/ps*fs + fm → sum = cnt*fm, sumsq = r^2 * sum (p-pm)^2 + cnt*fm^2
+                            // channel C + c (feature crop) = the accumulated sums themselves
+            const double r = (double)stat[3 * C + c] / (double)stat[C + c];
+            double dev = a1 - cnt * pm * pm;
+            if (dev < 0) dev = 0;
+            gsum[c] = cnt * fm;            gsum[2 * C + c] = r * r * dev + cnt * fm * fm;
+            gsum[C + c] = b0;              gsum[3 * C + c] = b1;
+        }
     }
     __syncthreads();
+    if (gn_scale) {         // GroupNorm(2C/32 groups) of the concatenated output (networks.py:508: norm1 of conv_*_fuse) → affine
+        const int G2 = 2 * C / 32;
+        for (int gq = t; gq < G2; gq += 256) {
+            double s1 = 0.0, s2 = 0.0;
+            for (int k = 0; k < 32; ++k) { s1 += gsum[gq * 32 + k]; s2 += gsum[2 * C + gq * 32 + k]; }
+            const double cnt = (double)npx * 32.0;
+            const double mean = s1 / cnt;
+            double var = s2 / cnt - mean * mean;
+            if (var < 0.0) var = 0.0;
+            gmr[2 * gq] = (float)mean; gmr[2 * gq + 1] = (float)(1.0 / sqrt(var + (double)gn_eps));
+        }
+        __syncthreads();
+        for (int c = t; c < 2 * C; c += 256) {
+            const float ga = gn_gamma[c] * gmr[2 * (c / 32) + 1];
+            gn_scale[(size_t)g * 2 * C + c] = ga;
+            gn_shift[(size_t)g * 2 * C + c] = gn_beta[c] - gmr[2 * (c / 32)] * ga;
+        }
+    }
     T* obase = out + (size_t)g * S * S * 2 * C;
     const int c0 = ch * N;
     for (int p = pl; p < S * S; p += plane) {
@@ -316,26 +347,44 @@ __global__ void __launch_bounds__(256) adain_crop_kernel(const T* __restrict__ p
     }
 }
 
-extern "C" int mnet_adain_crop_concat(const void* prior, const void* feat, void* out, int32_t dtype, int32_t G,
-                                      int32_t S, int32_t C, int32_t feat_w, const int32_t* g_img,
-                                      const int32_t* g_x1, const int32_t* g_y1, const int32_t* g_w, void* stream) {
+static int adain_launch(const void* prior, const void* feat, void* out, int32_t dtype, int32_t G, int32_t S, int32_t C,
+                        int32_t feat_w, const int32_t* g_img, const int32_t* g_x1, const int32_t* g_y1, const int32_t* g_w,
+                        const float* gamma, const float* beta, float eps, float* scale, float* shift, void* stream) {
     MNET_CHECK_ARG(prior && feat && out && g_img && g_x1 && g_y1 && g_w, "adain: null pointer");
     MNET_CHECK_ARG(G > 0 && S > 0 && C > 0 && feat_w >= S, "adain: bad geometry");
     MNET_CHECK_ARG(dtype == MNET_F32 || dtype == MNET_F16, "adain: bad dtype");
     const int N = dtype == MNET_F16 ? 8 : 4;
-    MNET_CHECK_ALIGN(C % N == 0 && 256 % (C / N) == 0 && aligned16(prior) && aligned16(feat) && aligned16(out),
+    MNET_CHECK_ALIGN(C % N == 0 && 256 % (C / N) == 0 && C % 32 == 0 && aligned16(prior) && aligned16(feat) && aligned16(out),
                      "adain: C=%d unsupported or unaligned", C);
-    const size_t lds = (size_t)256 * N * 4 * sizeof(double) + (size_t)4 * C * sizeof(float);
+    const size_t lds = (size_t)256 * N * 4 * sizeof(double) + (size_t)4 * C * sizeof(float) + (size_t)4 * C * sizeof(double) +
+                       (size_t)(2 * C / 32) * 2 * sizeof(float);
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     if (dtype == MNET_F16) {
-        hipFuncSetAttribute(reinterpret_cast<const void*>(adain_crop_kernel<f16>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipLaunchKernelGGL(adain_crop_kernel<f16>, dim3(G), dim3(256), lds, st, (const f16*)prior, (const f16*)feat, (f16*)out, S, C, feat_w, g_img, g_x1, g_y1, g_w);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(adain_crop_kernel<f16>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL(adain_crop_kernel<f16>, dim3(G), dim3(256), lds, st, (const f16*)prior, (const f16*)feat, (f16*)out, S, C, feat_w,
+                           g_img, g_x1, g_y1, g_w, gamma, beta, eps, scale, shift);
     } else {
-        hipFuncSetAttribute(reinterpret_cast<const void*>(adain_crop_kernel<float>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipLaunchKernelGGL(adain_crop_kernel<float>, dim3(G), dim3(256), lds, st, (const float*)prior, (const float*)feat, (float*)out, S, C, feat_w, g_img, g_x1, g_y1, g_w);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(adain_crop_kernel<float>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL(adain_crop_kernel<float>, dim3(G), dim3(256), lds, st, (const float*)prior, (const float*)feat, (float*)out, S, C, feat_w,
+                           g_img, g_x1, g_y1, g_w, gamma, beta, eps, scale, shift);
     }
     MNET_LAUNCH_CHECK("adain_crop");
     return MNET_OK;
+}
+
+extern "C" int mnet_adain_crop_concat(const void* prior, const void* feat, void* out, int32_t dtype, int32_t G,
+                                      int32_t S, int32_t C, int32_t feat_w, const int32_t* g_img,
+                                      const int32_t* g_x1, const int32_t* g_y1, const int32_t* g_w, void* stream) {
+    return adain_launch(prior, feat, out, dtype, G, S, C, feat_w, g_img, g_x1, g_y1, g_w, nullptr, nullptr, 0.f, nullptr, nullptr, stream);
+}
+
+extern "C" int mnet_adain_crop_concat_gn(const void* prior, const void* feat, void* out, int32_t dtype, int32_t G,
+                                         int32_t S, int32_t C, int32_t feat_w, const int32_t* g_img,
+                                         const int32_t* g_x1, const int32_t* g_y1, const int32_t* g_w,
+                                         const float* gamma, const float* beta, float eps, float* scale, float* shift,
+                                         void* stream) {
+    MNET_CHECK_ARG(gamma && beta && scale && shift, "adain_gn: null pointer");
+    return adain_launch(prior, feat, out, dtype, G, S, C, feat_w, g_img, g_x1, g_y1, g_w, gamma, beta, eps, scale, shift, stream);
 }
 
 // ============================================================================ ordered glyph scatter

@@ -388,10 +388,11 @@ class TSPSRNet(nn.Module, _Precision):
         h = self._c(pk, name + ".0", x, ops.ACT_LRELU, x1=x1, valid_w=valid_w)
         return self._c(pk, name + ".2", h, valid_w=valid_w)
 
-    def _res_block(self, pk, name, x, valid_w=None):
+    def _res_block(self, pk, name, x, valid_w=None, norm1_affine=None):
         """ResTextBlockV2 (networks.py:506-516): GN statistics → one elementwise normalise+swish pass → conv; the skip
-        (+1x1 conv_out) rides in the second conv's epilogue."""
-        s1, h1 = ops.groupnorm_affine(x, *pk[name + ".norm1"], 1e-6, valid_w)
+        (+1x1 conv_out) rides in the second conv's epilogue.  ``norm1_affine``: (scale, shift) of norm1 when the producer
+        of x already has them (the AdaIN kernel for the fuse blocks)."""
+        s1, h1 = norm1_affine if norm1_affine is not None else ops.groupnorm_affine(x, *pk[name + ".norm1"], 1e-6, valid_w)
         xs = ops.affine_act(x, s1, h1, swish=True)              # GN apply + swish once per element
         h = self._c(pk, name + ".conv1", xs, valid_w=valid_w)
         del xs
@@ -407,8 +408,10 @@ class TSPSRNet(nn.Module, _Precision):
         """All glyphs of the batch at one scale (networks.py:421-449 / :455-482)."""
         if tab.G == 0:
             return feat
-        cat = ops.adain_crop_concat(prior, feat, tab.g_img, tab.g_x1, tab.g_y1, tab.g_w)       # AdaIN + crop + cat
-        fused = self._res_block(pk, "conv_%s_fuse.0" % tag, cat, valid_w=tab.g_w)
+        # AdaIN + crop + cat, and norm1's GroupNorm affine of the result in closed form from the AdaIN statistics
+        cat, s1, h1 = ops.adain_crop_concat_gn(prior, feat, tab.g_img, tab.g_x1, tab.g_y1, tab.g_w,
+                                               *pk["conv_%s_fuse.0.norm1" % tag], 1e-6)
+        fused = self._res_block(pk, "conv_%s_fuse.0" % tag, cat, valid_w=tab.g_w, norm1_affine=(s1, h1))
         del cat
         sc = self._two(pk, "conv_%s_scale" % tag, fused, valid_w=tab.g_w)
         sh = self._two(pk, "conv_%s_shift" % tag, fused, valid_w=tab.g_w)

@@ -12,7 +12,7 @@ from ._lib import (ACT_GELU, ACT_LRELU, ACT_LRELU_SQRT2, ACT_NONE, ACT_RELU, ACT
                    MNET_F32, ConvDesc)
 
 __all__ = ["conv2d", "linear", "nchw_to_nhwc", "nhwc_to_nchw", "upsample2x", "affine_act", "groupnorm_affine",
-           "adain_crop_concat", "glyph_scatter_affine", "layernorm", "token_mix", "attention", "pixelnorm",
+           "adain_crop_concat", "adain_crop_concat_gn", "glyph_scatter_affine", "layernorm", "token_mix", "attention", "pixelnorm",
            "embed_gather", "demod", "argmax_rows", "convert", "fused_bias_act", "sr_postprocess", "stats",
            "ACT_NONE", "ACT_RELU", "ACT_LRELU", "ACT_LRELU_SQRT2", "ACT_TANH", "ACT_GELU", "ACT_SIGMOID"]
 
@@ -197,6 +197,23 @@ def adain_crop_concat(prior, feat, g_img, g_x1, g_y1, g_w):
     _lib.check(lib.mnet_adain_crop_concat(_p(prior), _p(feat), _p(out), _dt(prior), G, S, C, FW, _p(g_img), _p(g_x1),
                                           _p(g_y1), _p(g_w), _stream()), "mnet_adain_crop_concat")
     return out
+
+
+def adain_crop_concat_gn(prior, feat, g_img, g_x1, g_y1, g_w, gamma, beta, eps=1e-6):
+    """adain_crop_concat + the GroupNorm affine of its output (closed form from the AdaIN statistics) → (out, scale, shift)"""
+    lib = _lib.load()
+    _need_cuda(prior, feat, g_img, g_x1, g_y1, g_w, gamma, beta)
+    G, S, S2, C = prior.shape
+    B, FH, FW, FC = feat.shape
+    if S != S2 or FH != S or FC != C or prior.dtype != feat.dtype or gamma.numel() != 2 * C:
+        raise RuntimeError("adain_crop_concat_gn: shape mismatch prior %s feat %s" % (tuple(prior.shape), tuple(feat.shape)))
+    out = torch.empty((G, S, S, 2 * C), dtype=prior.dtype, device=prior.device)
+    scale = torch.empty((G, 2 * C), dtype=torch.float32, device=prior.device)
+    shift = torch.empty((G, 2 * C), dtype=torch.float32, device=prior.device)
+    _lib.check(lib.mnet_adain_crop_concat_gn(_p(prior), _p(feat), _p(out), _dt(prior), G, S, C, FW, _p(g_img), _p(g_x1),
+                                             _p(g_y1), _p(g_w), _p(gamma), _p(beta), eps, _p(scale), _p(shift), _stream()),
+               "mnet_adain_crop_concat_gn")
+    return out, scale, shift
 
 
 def glyph_scatter_affine(feat, scale, shift, g_start, g_x1, g_w):

@@ -232,6 +232,12 @@ def test_adain_crop_and_scatter(S, dtype):
         v = f.reshape(f.shape[0], f.shape[1], -1)
         return v.mean(2)[:, :, None, None], (v.var(2) + 1e-5).sqrt()[:, :, None, None]
 
+    # the same launch can also emit the GroupNorm affine of its output (closed form from the AdaIN statistics)
+    gamma, beta = _rnd((2 * C,), 29).abs() + 0.5, _rnd((2 * C,), 30) * 0.3
+    out2, gsc, gsh = ops.adain_crop_concat_gn(_nhwc(prior, dtype), _nhwc(feat, dtype), g_img.to(DEV), g_x1.to(DEV), g_y1.to(DEV),
+                                              g_w.to(DEV), gamma.to(DEV), beta.to(DEV), 1e-6)
+    torch.cuda.synchronize()
+    assert torch.equal(out2, out)
     for g, (b, x1, gw) in enumerate(windows):
         y1 = int(g_y1[g])
         cp, cl = prior[g:g + 1, :, :, y1:y1 + gw], feat[b:b + 1, :, :, x1:x1 + gw]
@@ -240,6 +246,12 @@ def test_adain_crop_and_scatter(S, dtype):
         ref = torch.cat(((cp - pm) / ps * ls + lm, cl), dim=1)
         _check("adain S=%d glyph %d %s" % (S, g, dtype), got[g:g + 1, :, :, :gw], ref, dtype, extra=2.0)
         assert (got[g, :, :, gw:] == 0).all()
+        v = ref.reshape(2 * C // 32, -1)                                    # GroupNorm(2C/32 groups) statistics of the exact output
+        mean, rstd = v.mean(1), (v.var(1, unbiased=False) + 1e-6).rsqrt()
+        ga = gamma * rstd.repeat_interleave(32)
+        want_sc, want_sh = ga, beta - mean.repeat_interleave(32) * ga
+        assert torch.allclose(gsc[g].cpu(), want_sc, rtol=2e-4, atol=1e-5), "GN scale, glyph %d" % g
+        assert torch.allclose(gsh[g].cpu(), want_sh, rtol=2e-3, atol=2e-4), "GN shift, glyph %d" % g
     # ordered scatter
     scale = _q(_rnd((G, C, S, S), 27), dtype)
     shift = _q(_rnd((G, C, S, S), 28), dtype)
