@@ -388,39 +388,45 @@ extern "C" int mnet_adain_crop_concat_gn(const void* prior, const void* feat, vo
 }
 
 // ============================================================================ ordered glyph scatter
+// grid (x-chunks of one feature row, image): a thread owns one 16-byte channel chunk of one COLUMN; the glyph that owns the
+// column (last glyph of the image whose window covers it) is looked up once and reused for all S rows
 template <typename T>
 __global__ void __launch_bounds__(256) glyph_scatter_kernel(const T* __restrict__ feat, const T* __restrict__ scale,
                                                             const T* __restrict__ shift, T* __restrict__ out,
                                                             int S, int C, int FW, const int* __restrict__ g_start,
-                                                            const int* __restrict__ g_x1, const int* __restrict__ g_w,
-                                                            long long total_chunks) {
+                                                            const int* __restrict__ g_x1, const int* __restrict__ g_w) {
     constexpr int N = Vec<T>::N;
     const int cpp = C / N;
-    for (long long id = (long long)blockIdx.x * blockDim.x + threadIdx.x; id < total_chunks;
-         id += (long long)gridDim.x * blockDim.x) {
-        const int ch = (int)(id % cpp);
-        long long pix = id / cpp;
-        const int x = (int)(pix % FW); pix /= FW;
-        const int y = (int)(pix % S);
-        const int b = (int)(pix / S);
-        int owner = -1, ox = 0;
-        for (int gg = g_start[b + 1] - 1; gg >= g_start[b]; --gg) {      // last writer wins
-            const int x1 = g_x1[gg];
-            if (x >= x1 && x < x1 + g_w[gg]) { owner = gg; ox = x - x1; break; }
-        }
-        const u32x4 raw = ldg16(feat + (size_t)id * N);
-        if (owner < 0) { stg16(out + (size_t)id * N, raw); continue; }
+    const int b = blockIdx.y;
+    const int id = blockIdx.x * 256 + threadIdx.x;                 // (x, ch) inside one row
+    if (id >= FW * cpp) return;
+    const int ch = id % cpp, x = id / cpp;
+    int owner = -1, ox = 0;
+    for (int gg = g_start[b + 1] - 1; gg >= g_start[b]; --gg) {    // last writer wins
+        const int x1 = g_x1[gg];
+        if (x >= x1 && x < x1 + g_w[gg]) { owner = gg; ox = x - x1; break; }
+    }
+    const size_t row = (size_t)FW * C;
+    const T* fp = feat + (size_t)b * S * row + (size_t)id * N;
+    T* op = out + (size_t)b * S * row + (size_t)id * N;
+    if (owner < 0) {
+#pragma unroll 4
+        for (int y = 0; y < S; ++y) stg16(op + (size_t)y * row, ldg16(fp + (size_t)y * row));
+        return;
+    }
+    const size_t go = ((size_t)owner * S * S + ox) * C + (size_t)ch * N;     // + y*S*C per row
+#pragma unroll 4
+    for (int y = 0; y < S; ++y) {
         float f[N], sc[N], sh[N], o[N];
-        Vec<T>::unpack(raw, f);
-        const size_t go = (((size_t)owner * S + y) * S + ox) * C + (size_t)ch * N;
-        Vec<T>::unpack(ldg16(scale + go), sc);
-        Vec<T>::unpack(ldg16(shift + go), sh);
+        Vec<T>::unpack(ldg16(fp + (size_t)y * row), f);
+        Vec<T>::unpack(ldg16(scale + go + (size_t)y * S * C), sc);
+        Vec<T>::unpack(ldg16(shift + go + (size_t)y * S * C), sh);
 #pragma unroll
         for (int j = 0; j < N; ++j) {
             const float r = __fadd_rn(__fmul_rn(f[j], sc[j]), sh[j]);    // res = f*scale + shift  (:448)
             o[j] = __fadd_rn(f[j], r);                                    // ori + res             (:449)
         }
-        stg16(out + (size_t)id * N, Vec<T>::pack(o));
+        stg16(op + (size_t)y * row, Vec<T>::pack(o));
     }
 }
 
@@ -433,11 +439,11 @@ extern "C" int mnet_glyph_scatter_affine(const void* feat, const void* scale, co
     const int N = dtype == MNET_F16 ? 8 : 4;
     MNET_CHECK_ALIGN(C % N == 0 && aligned16(feat) && aligned16(scale) && aligned16(shift) && aligned16(out),
                      "scatter: unaligned");
-    const long long total = (long long)B * S * feat_w * (C / N);
-    const int blocks = (int)((total + 255) / 256 < 16384 ? (total + 255) / 256 : 16384);
+    MNET_CHECK_ARG(B <= 65535, "scatter: too many images");
+    const int blocks = (int)(((long long)feat_w * (C / N) + 255) / 256);
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-    if (dtype == MNET_F16) hipLaunchKernelGGL(glyph_scatter_kernel<f16>, dim3(blocks), dim3(256), 0, st, (const f16*)feat, (const f16*)scale, (const f16*)shift, (f16*)out, S, C, feat_w, g_start, g_x1, g_w, total);
-    else hipLaunchKernelGGL(glyph_scatter_kernel<float>, dim3(blocks), dim3(256), 0, st, (const float*)feat, (const float*)scale, (const float*)shift, (float*)out, S, C, feat_w, g_start, g_x1, g_w, total);
+    if (dtype == MNET_F16) hipLaunchKernelGGL(glyph_scatter_kernel<f16>, dim3(blocks, B), dim3(256), 0, st, (const f16*)feat, (const f16*)scale, (const f16*)shift, (f16*)out, S, C, feat_w, g_start, g_x1, g_w);
+    else hipLaunchKernelGGL(glyph_scatter_kernel<float>, dim3(blocks, B), dim3(256), 0, st, (const float*)feat, (const float*)scale, (const float*)shift, (float*)out, S, C, feat_w, g_start, g_x1, g_w);
     MNET_LAUNCH_CHECK("glyph_scatter");
     return MNET_OK;
 }
