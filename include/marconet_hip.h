@@ -230,6 +230,14 @@ int mnet_convert(const void* src, int32_t src_dtype, void* dst, int32_t dst_dtyp
 int mnet_fused_bias_act(const float* x, const float* bias, float* y, int64_t total, int32_t C, int32_t inner,
                         float negative_slope, float scale, void* stream);
 
+/* 3x3 / stride 1 / pad 1 convolution of a cin = 64 map to 3 output channels + bias (+ tanh): the last layer of TSPSRNet
+ * (conv_final.6 + Tanh, models/networks.py:374-375).  x NHWC [n,h,w,64] (f16 or f32); wgt [3][3][3][64] (cout, kh, kw, cin) in
+ * the same dtype; bias fp32 [3]; act MNET_ACT_NONE or MNET_ACT_TANH.  Outputs (either may be NULL, not both): y_nhwc
+ * [n,h,w,8] in the input dtype (channels 3..7 zero) and y_nchw fp32 [n,3,h,w] — the tensor the module returns, without a
+ * separate layout pass (in f16 mode it holds the same f16-rounded values as y_nhwc). */
+int mnet_conv3x3_rgb(const void* x, int32_t dtype, int32_t n, int32_t h, int32_t w, int32_t cin, const void* wgt,
+                     const float* bias, int32_t act, void* y_nhwc, float* y_nchw, void* stream);
+
 /* K19, the script's output post-processing (test_sr.py:198-200): sr*0.5+0.5 → HWC → RGB→BGR → clip(0,1)*255.
  * src NHWC [npix][c_ld] (RGB in channels 0..2, f32 or f16); dst [npix][3] BGR as float32 (dst_u8 == 0: exactly what the
  * script hands to cv2.imwrite) or uint8 (dst_u8 != 0: cv2's float→uchar conversion, round half to even) — 4x fewer bytes

@@ -667,3 +667,122 @@ extern "C" int mnet_sr_postprocess(const void* src, int32_t src_dtype, void* dst
     MNET_LAUNCH_CHECK("sr_postprocess");
     return MNET_OK;
 }
+
+// ============================================================================ 3x3 conv to RGB (the last layer of TSPSRNet)
+// conv_final.6 + tanh (models/networks.py:374-375): 64 → 3 channels at 128 x 2048.  Through the implicit-GEMM kernel this
+// wastes a 16-wide MFMA tile on 3 outputs (1.84 ms per 64 images, 1.1 TB/s) and needs a separate NHWC→NCHW pass for the
+// fp32 image the module returns.  Here: one workgroup per 8 x 32 pixel tile, the (8+2) x (32+2) x Cin input patch staged in
+// LDS (XOR-swizzled 16-byte chunks, zero halo), one thread per output pixel, 3 fp32 accumulators, weights read through the
+// scalar cache (wave-uniform addresses).  f16: v_dot2_f32_f16 (the same exact f16 x f16 products as the MFMA path, fp32
+// sums); f32: plain fma.  Output: NHWC [N,H,W,8] in the input dtype and/or fp32 NCHW [N,3,H,W].
+template <typename T> struct RgbW;            // weight element as the kernel reads it
+template <> struct RgbW<f16> { typedef unsigned int pair_t; };   // two f16 packed
+template <> struct RgbW<float> { typedef float pair_t; };
+
+template <typename T, int CIN>
+__global__ void __launch_bounds__(256) conv3x3_rgb_kernel(const T* __restrict__ x, const void* __restrict__ wgt_,
+                                                          const float* __restrict__ bias, T* __restrict__ y_nhwc,
+                                                          float* __restrict__ y_nchw, int H, int W, int act) {
+    constexpr int TH = 8, TW = 32, PW = TW + 2, PH = TH + 2;
+    constexpr int ROWB = CIN * (int)sizeof(T);                 // bytes per pixel
+    constexpr int CH = ROWB / 16;                              // 16-byte chunks per pixel
+    constexpr int RPB = ROWB >= 256 ? 1 : 256 / ROWB;          // pixels per 256-byte LDS bank line
+    // chunk c of patch pixel q lives at q*ROWB + ((c ^ key(q)) * 16), key(q) = (q / RPB) & (CH-1): the 16 lanes of a
+    // ds_read_b128 group (16 consecutive pixels, same logical chunk) then hit 16 distinct 16-byte slots of the bank line(s)
+    auto lds_off = [](int q, int c) __attribute__((always_inline)) { return q * ROWB + ((c ^ ((q / RPB) & (CH - 1))) << 4); };
+    extern __shared__ __attribute__((aligned(16))) unsigned char dyn[];
+    const int t = threadIdx.x;
+    const int tiles_x = (W + TW - 1) / TW;
+    const int n = blockIdx.y, ty = blockIdx.x / tiles_x, tx = blockIdx.x - ty * tiles_x;
+    const int y0 = ty * TH - 1, x0 = tx * TW - 1;              // patch origin (halo included)
+    const T* xb = x + (size_t)n * H * W * CIN;
+    // stage the patch (zero halo outside the image)
+    for (int i = t; i < PH * PW * CH; i += 256) {
+        const int c = i % CH, q = i / CH;
+        const int py = q / PW, px = q - py * PW;
+        const int gy = y0 + py, gx = x0 + px;
+        u32x4 v = {0u, 0u, 0u, 0u};
+        if ((unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W) v = ldg16(xb + ((size_t)gy * W + gx) * CIN + c * (16 / (int)sizeof(T)));
+        *reinterpret_cast<u32x4*>(dyn + lds_off(q, c)) = v;
+    }
+    __syncthreads();
+    const int ly = t / TW, lx = t - ly * TW;
+    const int oy = ty * TH + ly, ox = tx * TW + lx;
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f;
+    if constexpr (sizeof(T) == 2) {
+        typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+        const unsigned* wp = reinterpret_cast<const unsigned*>(wgt_);        // [3][9][CIN/2] packed f16 pairs
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+            const int q = (ly + tap / 3) * PW + lx + tap % 3;
+#pragma unroll
+            for (int c = 0; c < CH; ++c) {
+                const u32x4 v = *reinterpret_cast<const u32x4*>(dyn + lds_off(q, c));
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const h2 xv = bitcast<h2>(v[j]);
+                    const int k = tap * (CIN / 2) + c * 4 + j;
+                    a0 = __builtin_amdgcn_fdot2(xv, bitcast<h2>(wp[k]), a0, false);
+                    a1 = __builtin_amdgcn_fdot2(xv, bitcast<h2>(wp[9 * (CIN / 2) + k]), a1, false);
+                    a2 = __builtin_amdgcn_fdot2(xv, bitcast<h2>(wp[18 * (CIN / 2) + k]), a2, false);
+                }
+            }
+        }
+    } else {
+        const float* wp = reinterpret_cast<const float*>(wgt_);              // [3][9][CIN]
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+            const int q = (ly + tap / 3) * PW + lx + tap % 3;
+#pragma unroll 4
+            for (int c = 0; c < CH; ++c) {
+                const f32x4 v = bitcast<f32x4>(*reinterpret_cast<const u32x4*>(dyn + lds_off(q, c)));
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int k = tap * CIN + c * 4 + j;
+                    a0 = fmaf(v[j], wp[k], a0); a1 = fmaf(v[j], wp[9 * CIN + k], a1); a2 = fmaf(v[j], wp[18 * CIN + k], a2);
+                }
+            }
+        }
+    }
+    if (oy >= H || ox >= W) return;
+    float r[8] = {a0 + bias[0], a1 + bias[1], a2 + bias[2], 0.f, 0.f, 0.f, 0.f, 0.f};
+    if (act == MNET_ACT_TANH) { r[0] = tanhf(r[0]); r[1] = tanhf(r[1]); r[2] = tanhf(r[2]); }
+    if (y_nhwc) {
+        T* yp = y_nhwc + (((size_t)n * H + oy) * W + ox) * 8;
+        if constexpr (sizeof(T) == 2) stg16(yp, Vec<f16>::pack(r));
+        else { stg16(yp, Vec<float>::pack(r)); stg16(yp + 4, Vec<float>::pack(r + 4)); }
+    }
+    if (y_nchw) {
+        // what the module hands back: fp32 NCHW; in f16 mode the values are the f16-rounded ones the NHWC tensor holds
+        const size_t plane = (size_t)H * W;
+        float* op = y_nchw + (size_t)n * 3 * plane + (size_t)oy * W + ox;
+#pragma unroll
+        for (int o = 0; o < 3; ++o) op[o * plane] = sizeof(T) == 2 ? (float)(f16)r[o] : r[o];
+    }
+}
+
+extern "C" int mnet_conv3x3_rgb(const void* x, int32_t dtype, int32_t n, int32_t h, int32_t w, int32_t cin, const void* wgt,
+                                const float* bias, int32_t act, void* y_nhwc, float* y_nchw, void* stream) {
+    MNET_CHECK_ARG(x && wgt && bias && (y_nhwc || y_nchw) && n > 0 && h > 0 && w > 0 && n <= 65535, "conv3x3_rgb: bad args");
+    MNET_CHECK_ARG(dtype == MNET_F32 || dtype == MNET_F16, "conv3x3_rgb: bad dtype");
+    MNET_CHECK_ARG(cin == 64, "conv3x3_rgb: cin=%d (supported: 64)", cin);
+    MNET_CHECK_ARG(act == MNET_ACT_NONE || act == MNET_ACT_TANH, "conv3x3_rgb: act %d", act);
+    MNET_CHECK_ALIGN(aligned16(x) && aligned16(y_nhwc) && aligned16(wgt), "conv3x3_rgb: unaligned pointer");
+    const int tiles = ((h + 7) / 8) * ((w + 31) / 32);
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    if (dtype == MNET_F16) {
+        const int lds = 10 * 34 * 64 * 2;
+        hipLaunchKernelGGL((conv3x3_rgb_kernel<f16, 64>), dim3(tiles, n), dim3(256), lds, st, (const f16*)x, wgt, bias, (f16*)y_nhwc, y_nchw, h, w, act);
+    } else {
+        const int lds = 10 * 34 * 64 * 4;
+        static thread_local bool attr_set = false;
+        if (!attr_set) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_rgb_kernel<float, 64>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+            if (e != hipSuccess) return mnet_fail(MNET_E_LAUNCH, "hipFuncSetAttribute(conv3x3_rgb): %s", hipGetErrorString(e));
+            attr_set = true;
+        }
+        hipLaunchKernelGGL((conv3x3_rgb_kernel<float, 64>), dim3(tiles, n), dim3(256), lds, st, (const float*)x, wgt, bias, (float*)y_nhwc, y_nchw, h, w, act);
+    }
+    MNET_LAUNCH_CHECK("conv3x3_rgb");
+    return MNET_OK;
+}

@@ -373,6 +373,9 @@ class TSPSRNet(nn.Module, _Precision):
         sn("conv_up.1", self.conv_up[1]); res("conv_up.3", self.conv_up[3]); sn("conv_up.4", self.conv_up[4])
         sn("conv_final.0", self.conv_final[0]); sn("conv_final.3", self.conv_final[3])
         res("conv_final.5", self.conv_final[5]); sn("conv_final.6", self.conv_final[6], cout_mult=RGB_PAD)
+        m6 = self.conv_final[6]                       # the same layer for the dedicated 64 → 3 kernel: [3][3][3][64], bias [3]
+        pk["conv_final.6.rgb"] = (sn_fold(m6.weight_orig, m6.weight_u, m6.weight_v).permute(0, 2, 3, 1).contiguous().to(dtype),
+                                  m6.bias.detach().float().contiguous())
         res("conv_32_fuse.0", self.conv_32_fuse[0]); res("conv_64_fuse.0", self.conv_64_fuse[0])
         return pk
 
@@ -447,11 +450,12 @@ class TSPSRNet(nn.Module, _Precision):
             counts64 = [int(p.shape[0]) for p in priors64] + [0] * (B - len(priors64))
             p32 = self._gather_priors(priors32, dtype, 512, 32) if sum(counts32) else None
             p64 = self._gather_priors(priors64, dtype, 256, 64) if sum(counts64) else None
-            return ops.nhwc_to_nchw(self.forward_packed(lq, p64, p32, counts64, counts32, locs), c=3)
+            return self.forward_packed(lq, p64, p32, counts64, counts32, locs, nchw_out=True)
 
-    def forward_packed(self, lq, p64, p32, counts64, counts32, locs):
+    def forward_packed(self, lq, p64, p32, counts64, counts32, locs, nchw_out=False):
         """batched entry: ``p64`` NHWC [ΣN,64,64,256] / ``p32`` NHWC [ΣN,32,32,512] hold the glyph priors of all
-        images back to back (``counts*[b]`` glyphs for image b).  Returns NHWC [B,128,2048,8] (RGB in channels 0-2)."""
+        images back to back (``counts*[b]`` glyphs for image b).  Returns NHWC [B,128,2048,8] (RGB in channels 0-2), or —
+        ``nchw_out`` — the reference's fp32 NCHW [B,3,128,2048] written by the last conv itself."""
         with torch.no_grad():
             pk = self._cache.get(self, self.precision, self._build)
             dtype = torch_dtype(self.precision)
@@ -486,4 +490,9 @@ class TSPSRNet(nn.Module, _Precision):
             del s64
             h = self._c(pk, "conv_final.3", ops.upsample2x(h), ops.ACT_LRELU)
             h = self._res_block(pk, "conv_final.5", h)
-            return self._c(pk, "conv_final.6", h, ops.ACT_TANH)
+            if h.shape[3] == 64:                      # conv_final.6 + tanh through the dedicated 3-output kernel
+                wr, br = pk["conv_final.6.rgb"]
+                y_nhwc, y_nchw = ops.conv3x3_rgb(h, wr, br, ops.ACT_TANH, nhwc=not nchw_out, nchw=nchw_out)
+                return y_nchw if nchw_out else y_nhwc
+            y = self._c(pk, "conv_final.6", h, ops.ACT_TANH)
+            return ops.nhwc_to_nchw(y, c=3) if nchw_out else y

@@ -13,7 +13,7 @@ from ._lib import (ACT_GELU, ACT_LRELU, ACT_LRELU_SQRT2, ACT_NONE, ACT_RELU, ACT
 
 __all__ = ["conv2d", "linear", "nchw_to_nhwc", "nhwc_to_nchw", "upsample2x", "affine_act", "groupnorm_affine",
            "adain_crop_concat", "adain_crop_concat_gn", "glyph_scatter_affine", "layernorm", "token_mix", "attention", "pixelnorm",
-           "embed_gather", "demod", "argmax_rows", "convert", "fused_bias_act", "sr_postprocess", "stats",
+           "embed_gather", "demod", "argmax_rows", "convert", "fused_bias_act", "sr_postprocess", "conv3x3_rgb", "stats",
            "ACT_NONE", "ACT_RELU", "ACT_LRELU", "ACT_LRELU_SQRT2", "ACT_TANH", "ACT_GELU", "ACT_SIGMOID"]
 
 
@@ -328,3 +328,17 @@ def sr_postprocess(y_nhwc, u8=True):
     _lib.check(lib.mnet_sr_postprocess(_p(y_nhwc), _dt(y_nhwc), _p(out), 1 if u8 else 0, b * h * w, c_ld, _stream()),
                "mnet_sr_postprocess")
     return out
+
+
+def conv3x3_rgb(x, wgt, bias, act=ACT_TANH, nhwc=True, nchw=False):
+    """conv_final.6 (+ tanh): x NHWC [N,H,W,64]; wgt [3,3,3,64] same dtype; bias fp32 [3] → NHWC [N,H,W,8] (same dtype)
+    and/or fp32 NCHW [N,3,H,W]; returns (y_nhwc or None, y_nchw or None)."""
+    lib = _lib.load()
+    _need_cuda(x, wgt, bias)
+    n, h, w, c = x.shape
+    if wgt.dtype != x.dtype or wgt.numel() != 3 * 9 * c:
+        raise RuntimeError("conv3x3_rgb: weight dtype/shape mismatch")
+    y1 = torch.empty((n, h, w, 8), dtype=x.dtype, device=x.device) if nhwc else None
+    y2 = torch.empty((n, 3, h, w), dtype=torch.float32, device=x.device) if nchw else None
+    _lib.check(lib.mnet_conv3x3_rgb(_p(x), _dt(x), n, h, w, c, _p(wgt), _p(bias), act, _p(y1), _p(y2), _stream()), "mnet_conv3x3_rgb")
+    return y1, y2

@@ -63,7 +63,9 @@ class MarconetPipeline:
             p64, p32 = ops.convert(p64, sr_dtype), ops.convert(p32, sr_dtype)
         else:
             p64 = p32 = None
-        y = self.sr.forward_packed(lq, p64, p32, counts, counts, locs)   # test_sr.py:197
+        if output != "u8_bgr" and not return_nhwc:
+            return self.sr.forward_packed(lq, p64, p32, counts, counts, locs, nchw_out=True)   # test_sr.py:197
+        y = self.sr.forward_packed(lq, p64, p32, counts, counts, locs)
         if output == "u8_bgr":                                           # test_sr.py:198-200 fused: [B,128,2048,3] uint8
             return ops.sr_postprocess(y, u8=True)
         return y if return_nhwc else ops.nhwc_to_nchw(y, c=3)
@@ -115,7 +117,7 @@ class MarconetPipeline:
                 a, c = p64.index_select(0, gt), p32.index_select(0, gt)
             else:
                 a = c = None
-            y = ops.nhwc_to_nchw(self.sr.forward_packed(lq_b, a, c, cb, cb, locs_b), c=3)
+            y = self.sr.forward_packed(lq_b, a, c, cb, cb, locs_b, nchw_out=True)
             for k, b in enumerate(idx):
                 out[b] = y[k]
         return out

@@ -548,3 +548,20 @@ def test_sr_postprocess_matches_script(dtype):
     got_u = ops.sr_postprocess(y.to(DEV), u8=True).cpu().numpy()
     assert np.array_equal(got_f, want.astype(np.float32))
     assert np.array_equal(got_u, np.rint(want).astype(np.uint8))
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float16])
+@pytest.mark.parametrize("shape", [(2, 8, 32), (3, 19, 45), (1, 128, 2048)])
+def test_conv3x3_rgb_kernel(dtype, shape):
+    """conv_final.6 + tanh through the dedicated 64 → 3 kernel (NHWC and fp32-NCHW outputs) vs F.conv2d, incl. partial tiles"""
+    ops = _ops()
+    n, h, w = shape
+    x = _q(_rnd((n, 64, h, w), 301), dtype)
+    wt = _q(_rnd((3, 64, 3, 3), 302, 1.0 / math.sqrt(576)), dtype)
+    bias = _rnd((3,), 303, 0.2)
+    ref = torch.tanh(F.conv2d(x, wt, bias=bias, padding=1))
+    y_nhwc, y_nchw = ops.conv3x3_rgb(_nhwc(x, dtype), _pack_w(wt, dtype), bias.to(DEV), ops.ACT_TANH, nhwc=True, nchw=True)
+    torch.cuda.synchronize()
+    _check("conv3x3_rgb nhwc %s %s" % (shape, dtype), _nchw(y_nhwc)[:, :3], ref, dtype, extra=2.0)
+    assert float(y_nhwc[..., 3:].abs().max()) == 0.0
+    assert torch.equal(y_nchw.cpu(), _nchw(y_nhwc)[:, :3].contiguous())
