@@ -195,11 +195,13 @@ class TextGenerator(nn.Module):
         return pk
 
     # ------------------------------------------------------------------ forward pieces
-    @staticmethod
-    def _style(L, S):
+    def _style(self, L, S):
         """this layer's slice of the batched modulation EqualLinear (:283) and its demodulation table
         rsqrt(Σ (scale·W·s)² + 1e-8) (:286)"""
         s = S[:, L["mod_off"]:L["mod_off"] + L["cin"]].contiguous()
+        if getattr(self, "_gidx", None) is not None:      # demodulation once per distinct style, gathered per glyph
+            su = self._lat_u[:, L["mod_off"]:L["mod_off"] + L["cin"]].contiguous()
+            return s, ops.demod(su, L["wsq_t"]).index_select(0, self._gidx)
         return s, ops.demod(s, L["wsq_t"])
 
     @staticmethod
@@ -217,8 +219,11 @@ class TextGenerator(nn.Module):
             skip = ops.upsample2x(skip)                                        # :318-319
         return ops.conv2d(x, L["w"], RGB_PAD, in_scale=s, bias=L["bias"], residual=skip, act=ops.ACT_TANH)
 
-    def forward_nhwc(self, styles, labels, need_image=True):
+    def forward_nhwc(self, styles, labels, need_image=True, style_index=None):
         """→ (image NHWC [N,128,128c,8], prior64 NHWC [N,64,64c,256], prior32 NHWC [N,32,32c,512]).
+        ``style_index`` (int64 [N], optional): ``styles`` then holds only the DISTINCT style vectors (one per image in
+        test_sr.py:183, where every glyph of an image gets the same w) and glyph i uses styles[style_index[i]] — the style
+        MLP, the 17 modulations and the 11 demodulation tables run once per distinct style and are gathered per glyph.
         ``need_image=False`` (opt-in, batched SR driver only) stops after the 64-px level: the 128-px level feeds nothing
         but the visualisation image (models/networks.py:148-164; 35 % of the generator's FLOPs) and ``image`` is None."""
         pk = self._cache.get(self, self.precision, self._build)
@@ -228,6 +233,13 @@ class TextGenerator(nn.Module):
             lat = ops.linear(lat, w, self.style_dim, bias=b, act=ops.ACT_LRELU_SQRT2)
         x = ops.embed_gather(pk["emb"], labels, dtype, self.class_num)         # SelectText (:205-215)
         lat = ops.linear(lat, pk["mod_all_w"], pk["mod_total"], bias=pk["mod_all_b"])    # every layer's modulation at once
+        if style_index is not None:
+            # per-style rows → per-glyph rows (pure gathers).  _style() slices `lat`; the demod tables are computed on the
+            # distinct rows and gathered through `self._gidx`
+            self._gidx, self._lat_u = style_index, lat
+            lat = lat.index_select(0, style_index)
+        else:
+            self._gidx = self._lat_u = None
         s, d = self._style(pk["conv1"], lat)
         x = self._styled(pk["conv1"], x, s, d, premodulated=False)
         skip = self._to_rgb(pk["rgb1"], x, lat, None) if need_image else None

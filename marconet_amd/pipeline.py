@@ -14,6 +14,10 @@ from . import ops
 from .packing import torch_dtype
 
 
+import os as _os
+_NO_STYLE_DEDUPE = bool(int(_os.environ.get("MNET_NO_STYLE_DEDUPE", "0")))      # A/B knob
+
+
 class MarconetPipeline:
     def __init__(self, encoder, gan, sr, precision="fp16", glyph_chunk=1024, need_prior_image=True):
         self.encoder, self.gan, self.sr = encoder, gan, sr
@@ -50,11 +54,17 @@ class MarconetPipeline:
                 raise RuntimeError("label index out of range [0,%d)" % tg.class_num)
             lab = lab.to(dev).contiguous()
             img_of = torch.repeat_interleave(torch.arange(B), torch.tensor(counts)).to(dev)
-            styles = w.index_select(0, img_of).contiguous()           # w0.repeat(n,1) per image (test_sr.py:183)
+            # w0.repeat(n,1) per image (test_sr.py:183): the generator gets the B distinct styles + the glyph→image index
             p64s, p32s = [], []
             for s in range(0, lab.shape[0], self.glyph_chunk):        # bounded working set for huge batches
-                _, a, c = tg.forward_nhwc(styles[s:s + self.glyph_chunk].contiguous(), lab[s:s + self.glyph_chunk].contiguous(),
-                                          need_image=self.need_prior_image)
+                if _NO_STYLE_DEDUPE:
+                    _, a, c = tg.forward_nhwc(w.index_select(0, img_of[s:s + self.glyph_chunk]).contiguous(),
+                                              lab[s:s + self.glyph_chunk].contiguous(), need_image=self.need_prior_image)
+                    p64s.append(a)
+                    p32s.append(c)
+                    continue
+                _, a, c = tg.forward_nhwc(w, lab[s:s + self.glyph_chunk].contiguous(), need_image=self.need_prior_image,
+                                          style_index=img_of[s:s + self.glyph_chunk].contiguous())
                 p64s.append(a)
                 p32s.append(c)
             p64 = p64s[0] if len(p64s) == 1 else torch.cat(p64s)

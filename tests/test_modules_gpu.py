@@ -344,3 +344,20 @@ def test_full_size_batch_properties_fp16(nets):
         assert torch.equal(shuffled, full.index_select(0, pt))
     finally:
         pipe.set_precision("fp32")
+
+
+def test_generator_distinct_styles_equal_expanded(nets):
+    """style_index (distinct styles + glyph→style map, what the batched driver passes) == one style row per glyph, bit for bit"""
+    tg = nets[1].TextGenerator
+    for prec in ("fp32", "fp16"):
+        nets[1].set_precision(prec)
+        tg.precision = prec
+        w = synth.make_styles(111, 3).to(DEV)
+        idx = torch.tensor([0, 0, 1, 2, 2, 2, 1], device=DEV)
+        lab = synth.make_labels(112, 7).to(DEV)
+        a = tg.forward_nhwc(w, lab, style_index=idx)
+        b = tg.forward_nhwc(w.index_select(0, idx).contiguous(), lab)
+        torch.cuda.synchronize()
+        for u, v in zip(a, b):
+            assert torch.equal(u, v)
+    nets[1].set_precision("fp32")
