@@ -155,11 +155,12 @@ def clear_labels_batch(logits):
     → list of B int64 tensors [n_b, 1] (CPU)."""
     B, T, C = logits.shape
     idx = ops.argmax_rows(logits.reshape(B * T, C).contiguous().float()).reshape(B, T).cpu().tolist()
-    out = []
-    for row in idx:
-        keep = [v for i, v in enumerate(row) if not (i > 0 and row[i - 1] == v) and v < ALPHABET_SIZE]
-        out.append(torch.tensor(keep, dtype=torch.int64).reshape(-1, 1))
-    return out
+    return [torch.tensor(collapse_indices(row), dtype=torch.int64).reshape(-1, 1) for row in idx]
+
+
+def collapse_indices(row, alphabet_size=ALPHABET_SIZE):
+    """the CTC-style collapse of test_w.py:37-39 on one row of argmax indices: drop repeats, drop blanks (>= alphabet size)"""
+    return [v for i, v in enumerate(row) if not (i > 0 and row[i - 1] == v) and v < alphabet_size]
 
 
 def locs_from_left_right(locs_lr):

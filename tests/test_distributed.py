@@ -93,3 +93,20 @@ def test_balance_shards_for_mixed_widths():
         assert sorted(b for p_ in parts for b in p_) == list(range(len(widths)))
         loads = [sum(f(b) for b in p_) for p_ in parts]
         assert max(loads) - min(loads) <= max(f(b) for b in range(len(widths))) + 1e-9
+
+
+def test_host_side_label_and_loc_helpers():
+    """collapse_indices == the oracle's clear_labels on the same logits; (left,right) → (centre, half-width) conversion"""
+    import random
+    import torch
+    from marconet_amd.pipeline import collapse_indices, locs_from_left_right
+    from oracle import marconet_oracle as O
+    rng = random.Random(5)
+    for _ in range(20):
+        idx = [rng.choice([3, 3, 7, 6735, 6735, 12, 6734]) for _ in range(64)]
+        logits = torch.full((64, 6736), -1.0)
+        logits[torch.arange(64), torch.tensor(idx)] = 1.0
+        assert collapse_indices(idx) == O.clear_labels(logits)
+    lr = torch.rand(3, 32)
+    out = locs_from_left_right(lr)
+    assert torch.allclose(out[:, 0::2], (lr[:, 1::2] + lr[:, 0::2]) / 2) and torch.allclose(out[:, 1::2], (lr[:, 1::2] - lr[:, 0::2]) / 2)
