@@ -68,6 +68,30 @@ def test_argument_validation_without_device():
     d.ho = 4
     assert lib.mnet_conv2d_flops(ctypes.byref(d)) == 2.0 * 4 * 4 * 4 * 8 * 9 * 16
     assert lib.mnet_layernorm(None, None, None, None, 1, 1, 1e-5, None) == -1
+    # the plan query resolves kernels without launching: an f16 3x3 conv with cin % 64 == 0 and >= 65536 pixels
+    d2 = _lib.ConvDesc()
+    d2.dtype = 1; d2.x0 = 16; d2.wgt = 16; d2.y = 16; d2.n = 64; d2.h = d2.ho = 32; d2.w = d2.wo = 32
+    d2.c0 = 64; d2.kh = d2.kw = 3; d2.stride_h = d2.stride_w = 1; d2.pad_h = d2.pad_w = 1
+    d2.cout = 256
+    assert lib.mnet_conv2d_plan(ctypes.byref(d2), _lib.ALGO_AUTO) == _lib.ALGO_DMA_CFG0            # 256x256 LDS-DMA tile
+    assert lib.mnet_conv2d_plan(ctypes.byref(d2), _lib.ALGO_STRIP_CFG0) == _lib.ALGO_STRIP_CFG0    # strip form by explicit request
+    d2.cout = 64
+    assert lib.mnet_conv2d_plan(ctypes.byref(d2), _lib.ALGO_AUTO) == _lib.ALGO_STRIP_CFG0 + 1      # strip kernel, 64x512 tile
+    d2.cout = 128
+    assert lib.mnet_conv2d_plan(ctypes.byref(d2), _lib.ALGO_AUTO) == _lib.ALGO_DMA_CFG0 + 4        # 128x512 tile
+    d2.n = 4                                                                                       # 4096 pixels: small-launch tile
+    assert lib.mnet_conv2d_plan(ctypes.byref(d2), _lib.ALGO_AUTO) == _lib.ALGO_DMA_CFG0 + 2
+    d2.c0 = 32
+    assert lib.mnet_conv2d_plan(ctypes.byref(d2), _lib.ALGO_AUTO) == _lib.ALGO_REG_STAGED          # cin % 64 != 0
+    assert lib.mnet_conv2d_plan(ctypes.byref(d2), _lib.ALGO_LDS_DMA) == -1
+    d2.c0 = 64; d2.dtype = 0
+    assert lib.mnet_conv2d_plan(ctypes.byref(d2), _lib.ALGO_AUTO) == _lib.ALGO_REG_STAGED          # fp32
+    # argument checks of the newer entry points (all before any HIP call)
+    assert lib.mnet_conv3x3_rgb(16, 1, 1, 8, 8, 32, 16, 16, 4, 16, None, None) == -1 and b"cin" in lib.mnet_last_error()
+    assert lib.mnet_conv3x3_rgb(16, 1, 1, 8, 8, 64, 16, 16, 4, None, None, None) == -1            # no output requested
+    assert lib.mnet_sr_postprocess(None, 1, 16, 1, 10, 8, None) == -1
+    assert lib.mnet_sr_postprocess(16, 1, 16, 1, 10, 2, None) == -1                                # fewer than 3 channels
+    assert lib.mnet_adain_crop_concat_gn(16, 16, 16, 1, 1, 32, 256, 512, 16, 16, 16, 16, None, None, 1e-6, None, None, None) == -1
 
 
 def test_ops_refuse_cpu_tensors():
