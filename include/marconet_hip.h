@@ -105,7 +105,10 @@ int mnet_conv2d_nhwc(const mnet_conv_desc* d, void* stream);
  *      the register-staged kernel walks k tap-outer (same products, fp32 partial sums associated differently)
  *   id 7/8/9: ids 0/4/5 on v_mfma_f32_32x32x16_f16 (experimental)
  *   id 11-15: diagnostic builds used by tools/wg_timeline.py and tools/conv_bench.py; they produce WRONG results */
-enum { MNET_CONV_ALGO_AUTO = 0, MNET_CONV_ALGO_REG_STAGED = 1, MNET_CONV_ALGO_LDS_DMA = 2, MNET_CONV_ALGO_DMA_CFG0 = 16,
+enum { MNET_CONV_ALGO_AUTO = 0, MNET_CONV_ALGO_REG_STAGED = 1, MNET_CONV_ALGO_LDS_DMA = 2,
+       MNET_CONV_ALGO_SKINNY = 3 /* fp32 1x1 over <= 512 pixels straight from global memory (the TextViT linears of a small batch;
+                                  * 16 x 64 tiles).  AUTO uses it when eligible; bit-identical to REG_STAGED. */,
+       MNET_CONV_ALGO_DMA_CFG0 = 16,
        MNET_CONV_ALGO_STRIP_CFG0 = 32 /* + id: the 3x3 "strip" LDS-DMA kernel (one activation strip per filter row shared by its
                                         * three taps; id 0: 256x256 tile, id 1: 64x512 tile).  Eligible: 3x3/stride 1/pad 1, one
                                         * source, cout >= 256 (id 0) or < 128 (id 1), >= 65536 output pixels, whole-row tiles.
@@ -114,7 +117,15 @@ enum { MNET_CONV_ALGO_AUTO = 0, MNET_CONV_ALGO_REG_STAGED = 1, MNET_CONV_ALGO_LD
                                             * persistent grid (A/B measurements only; same results) */ };
 int mnet_conv2d_nhwc_ex(const mnet_conv_desc* d, int32_t algo, void* stream);
 
-/* which kernel `algo` resolves to for this launch, without launching: MNET_CONV_ALGO_REG_STAGED or
+/* split-K form of the skinny kernel for a "patchify" conv (filter == stride, no padding; fp32; <= 512 output pixels) — the
+ * TextViT patch embedding of a small batch (8x8 / stride 8 over [B,8,512,512]: K = 32768, 64 tokens per strip: one workgroup
+ * per 16 channels would stream 2 MiB of weights alone).  K is cut into `ksplit` contiguous slices (a multiple of kh; each a
+ * whole number of 16-float steps of one filter row), raw fp32 partial sums go to workspace [ksplit][n*ho*wo][cout] and a
+ * second launch folds them in slice order and applies the epilogue — deterministic; differs from mnet_conv2d_nhwc only in
+ * the association of the fp32 sum. */
+int mnet_conv2d_splitk(const mnet_conv_desc* d, int32_t ksplit, float* workspace, void* stream);
+
+/* which kernel `algo` resolves to for this launch, without launching: MNET_CONV_ALGO_REG_STAGED, MNET_CONV_ALGO_SKINNY,
  * MNET_CONV_ALGO_DMA_CFG0 + id or MNET_CONV_ALGO_STRIP_CFG0 + id; negative MNET_E_* on invalid arguments (bench.py buckets
  * its timings by this) */
 int mnet_conv2d_plan(const mnet_conv_desc* d, int32_t algo);
@@ -178,6 +189,16 @@ int mnet_adain_crop_concat_gn(const void* prior, const void* feat, void* out, in
                               int32_t S, int32_t C, int32_t feat_w, const int32_t* g_img,
                               const int32_t* g_x1, const int32_t* g_y1, const int32_t* g_w,
                               const float* gamma, const float* beta, float eps, float* scale, float* shift, void* stream);
+
+/* the same result from three launches that spread each glyph over `slices` workgroups — for FEW glyphs (one strip at a time:
+ * the one-workgroup-per-glyph kernel above is then a 380 us latency chain).  gamma/beta/scale/shift may all be NULL (no
+ * GroupNorm affine).  Scratch owned by the caller: partial fp64 [G][slices][C][4], stat fp32 [G][4][C].  Agrees with the
+ * fused kernel up to the association of the fp64 statistic sums. */
+int mnet_adain_crop_concat_split(const void* prior, const void* feat, void* out, int32_t dtype, int32_t G,
+                                 int32_t S, int32_t C, int32_t feat_w, const int32_t* g_img,
+                                 const int32_t* g_x1, const int32_t* g_y1, const int32_t* g_w,
+                                 const float* gamma, const float* beta, float eps, float* scale, float* shift,
+                                 double* partial, float* stat, int32_t slices, void* stream);
 
 /* K13 ordered scatter:  out[b,y,x,:] = feat + (feat*scale[g,y,x-x1,:] + shift[g,y,x-x1,:]) for the LAST
  * glyph g of image b whose window covers x (later glyph overwrites earlier, :448,481); out = feat where

@@ -11,7 +11,7 @@ LIB_PATH = os.environ.get("MARCONET_HIP_LIB", os.path.join(_HERE, "lib", "libmar
 
 MNET_F32, MNET_F16 = 0, 1
 ACT_NONE, ACT_RELU, ACT_LRELU, ACT_LRELU_SQRT2, ACT_TANH, ACT_GELU, ACT_SIGMOID = range(7)
-ALGO_AUTO, ALGO_REG_STAGED, ALGO_LDS_DMA, ALGO_DMA_CFG0, ALGO_STRIP_CFG0, ALGO_FLAG_ONE_TILE = 0, 1, 2, 16, 32, 256
+ALGO_AUTO, ALGO_REG_STAGED, ALGO_LDS_DMA, ALGO_SKINNY, ALGO_DMA_CFG0, ALGO_STRIP_CFG0, ALGO_FLAG_ONE_TILE = 0, 1, 2, 3, 16, 32, 256
 
 c_int, c_void_p, c_float, c_double, c_i64 = ctypes.c_int32, ctypes.c_void_p, ctypes.c_float, ctypes.c_double, ctypes.c_int64
 
@@ -43,6 +43,7 @@ SYMBOLS = {
     "mnet_abi_version": (c_int, []),
     "mnet_conv2d_nhwc": (c_int, [ctypes.POINTER(ConvDesc), c_void_p]),
     "mnet_conv2d_nhwc_ex": (c_int, [ctypes.POINTER(ConvDesc), c_int, c_void_p]),
+    "mnet_conv2d_splitk": (c_int, [ctypes.POINTER(ConvDesc), c_int, c_void_p, c_void_p]),
     "mnet_conv2d_plan": (c_int, [ctypes.POINTER(ConvDesc), c_int]),
     "mnet_conv2d_flops": (c_double, [ctypes.POINTER(ConvDesc)]),
     "mnet_nchw_to_nhwc": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
@@ -56,6 +57,9 @@ SYMBOLS = {
                                        c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "mnet_adain_crop_concat_gn": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int,
                                           c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_void_p, c_void_p]),
+    "mnet_adain_crop_concat_split": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int,
+                                             c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_void_p,
+                                             c_void_p, c_void_p, c_int, c_void_p]),
     "mnet_glyph_scatter_affine": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int,
                                           c_void_p, c_void_p, c_void_p, c_void_p]),
     "mnet_layernorm": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_float, c_void_p]),

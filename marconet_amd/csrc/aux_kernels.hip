@@ -359,12 +359,13 @@ static int adain_launch(const void* prior, const void* feat, void* out, int32_t 
     const size_t lds = (size_t)256 * N * 4 * sizeof(double) + (size_t)4 * C * sizeof(float) + (size_t)4 * C * sizeof(double) +
                        (size_t)(2 * C / 32) * 2 * sizeof(float);
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    static thread_local size_t lds_set[2] = {0, 0};                    // attribute raised once per size (not during graph capture replays)
     if (dtype == MNET_F16) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(adain_crop_kernel<f16>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (lds > lds_set[1]) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(adain_crop_kernel<f16>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); lds_set[1] = lds; }
         hipLaunchKernelGGL(adain_crop_kernel<f16>, dim3(G), dim3(256), lds, st, (const f16*)prior, (const f16*)feat, (f16*)out, S, C, feat_w,
                            g_img, g_x1, g_y1, g_w, gamma, beta, eps, scale, shift);
     } else {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(adain_crop_kernel<float>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (lds > lds_set[0]) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(adain_crop_kernel<float>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); lds_set[0] = lds; }
         hipLaunchKernelGGL(adain_crop_kernel<float>, dim3(G), dim3(256), lds, st, (const float*)prior, (const float*)feat, (float*)out, S, C, feat_w,
                            g_img, g_x1, g_y1, g_w, gamma, beta, eps, scale, shift);
     }
@@ -385,6 +386,183 @@ extern "C" int mnet_adain_crop_concat_gn(const void* prior, const void* feat, vo
                                          void* stream) {
     MNET_CHECK_ARG(gamma && beta && scale && shift, "adain_gn: null pointer");
     return adain_launch(prior, feat, out, dtype, G, S, C, feat_w, g_img, g_x1, g_y1, g_w, gamma, beta, eps, scale, shift, stream);
+}
+
+// ---------------------------------------------------------------------------- the same in three launches for FEW glyphs
+// One workgroup per glyph walks its window as a chain of exposed load latencies (≈380 us for a 64x64x256 window): fine when a
+// thousand glyphs share the chip (batch 64: the kernel is HBM-bound), but a single strip has 16.  Here `slices` workgroups share
+// a glyph: (1) per-slice fp64 partial sums, (2) one workgroup per glyph folds them in slice order into the AdaIN statistics and
+// the GroupNorm affine, (3) `slices` workgroups write the output.  The arithmetic per element is the fused kernel's; only the
+// association of the fp64 sums differs (slice-major instead of lane-major), i.e. results agree to fp64 rounding of the sums.
+template <typename T>
+__global__ void __launch_bounds__(256) adain_stats_kernel(const T* __restrict__ prior, const T* __restrict__ feat, int S, int C, int FW,
+                                                          const int* __restrict__ g_img, const int* __restrict__ g_x1,
+                                                          const int* __restrict__ g_y1, const int* __restrict__ g_w,
+                                                          double* __restrict__ partial, int slices) {
+    constexpr int N = Vec<T>::N;
+    extern __shared__ __attribute__((aligned(16))) unsigned char dyn[];
+    double* red = reinterpret_cast<double*>(dyn);                       // [256][N][4]
+    const int g = blockIdx.y, sl = blockIdx.x, t = threadIdx.x;
+    const int cpp = C / N, plane = 256 / cpp;
+    const int ch = t % cpp, pl = t / cpp;
+    const int img = g_img[g], x1 = g_x1[g], y1 = g_y1[g], gw = g_w[g];
+    const T* pbase = prior + (size_t)g * S * S * C + (size_t)ch * N;
+    const T* fbase = feat + (size_t)img * S * FW * C + (size_t)ch * N;
+    const int npx = S * gw, per = (npx + slices - 1) / slices;
+    const int p_end = min(npx, (sl + 1) * per);
+    double ps_[N], pss[N], fs_[N], fss[N];
+#pragma unroll
+    for (int j = 0; j < N; ++j) { ps_[j] = pss[j] = fs_[j] = fss[j] = 0.0; }
+    for (int p = sl * per + pl; p < p_end; p += plane) {
+        const int y = p / gw, x = p - y * gw;
+        float a[N], b[N];
+        Vec<T>::unpack(ldg16(pbase + ((size_t)y * S + (y1 + x)) * C), a);
+        Vec<T>::unpack(ldg16(fbase + ((size_t)y * FW + (x1 + x)) * C), b);
+#pragma unroll
+        for (int j = 0; j < N; ++j) {
+            ps_[j] += (double)a[j]; pss[j] += (double)a[j] * (double)a[j];
+            fs_[j] += (double)b[j]; fss[j] += (double)b[j] * (double)b[j];
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < N; ++j) {
+        double* r = red + ((size_t)t * N + j) * 4;
+        r[0] = ps_[j]; r[1] = pss[j]; r[2] = fs_[j]; r[3] = fss[j];
+    }
+    __syncthreads();
+    for (int c = t; c < C; c += 256) {
+        const int chn = c / N, j = c % N;
+        double a0 = 0, a1 = 0, b0 = 0, b1 = 0;
+        for (int q = 0; q < plane; ++q) {
+            const double* r = red + ((size_t)(q * cpp + chn) * N + j) * 4;
+            a0 += r[0]; a1 += r[1]; b0 += r[2]; b1 += r[3];
+        }
+        double* o = partial + (((size_t)g * slices + sl) * C + c) * 4;
+        o[0] = a0; o[1] = a1; o[2] = b0; o[3] = b1;
+    }
+}
+
+// one workgroup per glyph: stat[g][4][C] = (prior mean, prior std, feature mean, feature std) and the GroupNorm affine
+__global__ void __launch_bounds__(256) adain_finalize_kernel(const double* __restrict__ partial, int slices, int S, int C,
+                                                             const int* __restrict__ g_w, float* __restrict__ stat,
+                                                             const float* __restrict__ gn_gamma, const float* __restrict__ gn_beta,
+                                                             float gn_eps, float* __restrict__ gn_scale, float* __restrict__ gn_shift) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char dyn[];
+    double* gsum = reinterpret_cast<double*>(dyn);                       // [2][2C]
+    float* gmr = reinterpret_cast<float*>(gsum + 4 * C);                 // [2C/32][2]
+    const int g = blockIdx.x, t = threadIdx.x;
+    const int npx = S * g_w[g];
+    float* st = stat + (size_t)g * 4 * C;
+    for (int c = t; c < C; c += 256) {
+        double a0 = 0, a1 = 0, b0 = 0, b1 = 0;
+        for (int sl = 0; sl < slices; ++sl) {
+            const double* r = partial + (((size_t)g * slices + sl) * C + c) * 4;
+            a0 += r[0]; a1 += r[1]; b0 += r[2]; b1 += r[3];
+        }
+        const double cnt = (double)npx;
+        const double pm = a0 / cnt, fm = b0 / cnt;
+        double pv = (a1 - cnt * pm * pm) / (cnt - 1.0), fv = (b1 - cnt * fm * fm) / (cnt - 1.0);
+        if (pv < 0) pv = 0; if (fv < 0) fv = 0;
+        const float psd = sqrtf((float)pv + 1e-5f), fsd = sqrtf((float)fv + 1e-5f);
+        st[c] = (float)pm; st[C + c] = psd; st[2 * C + c] = (float)fm; st[3 * C + c] = fsd;
+        if (gn_scale) {
+            const double r = (double)fsd / (double)psd;
+            double dev = a1 - cnt * pm * pm;
+            if (dev < 0) dev = 0;
+            gsum[c] = cnt * fm;            gsum[2 * C + c] = r * r * dev + cnt * fm * fm;
+            gsum[C + c] = b0;              gsum[3 * C + c] = b1;
+        }
+    }
+    if (!gn_scale) return;
+    __syncthreads();
+    const int G2 = 2 * C / 32;
+    for (int gq = t; gq < G2; gq += 256) {
+        double s1 = 0.0, s2 = 0.0;
+        for (int k = 0; k < 32; ++k) { s1 += gsum[gq * 32 + k]; s2 += gsum[2 * C + gq * 32 + k]; }
+        const double cnt = (double)npx * 32.0;
+        const double mean = s1 / cnt;
+        double var = s2 / cnt - mean * mean;
+        if (var < 0.0) var = 0.0;
+        gmr[2 * gq] = (float)mean; gmr[2 * gq + 1] = (float)(1.0 / sqrt(var + (double)gn_eps));
+    }
+    __syncthreads();
+    for (int c = t; c < 2 * C; c += 256) {
+        const float ga = gn_gamma[c] * gmr[2 * (c / 32) + 1];
+        gn_scale[(size_t)g * 2 * C + c] = ga;
+        gn_shift[(size_t)g * 2 * C + c] = gn_beta[c] - gmr[2 * (c / 32)] * ga;
+    }
+}
+
+template <typename T>
+__global__ void __launch_bounds__(256) adain_apply_kernel(const T* __restrict__ prior, const T* __restrict__ feat, T* __restrict__ out,
+                                                          int S, int C, int FW, const int* __restrict__ g_img,
+                                                          const int* __restrict__ g_x1, const int* __restrict__ g_y1,
+                                                          const int* __restrict__ g_w, const float* __restrict__ stat_g, int slices) {
+    constexpr int N = Vec<T>::N;
+    extern __shared__ __attribute__((aligned(16))) unsigned char dyn[];
+    float* stat = reinterpret_cast<float*>(dyn);                         // [4][C]
+    const int g = blockIdx.y, sl = blockIdx.x, t = threadIdx.x;
+    const int cpp = C / N, plane = 256 / cpp;
+    const int ch = t % cpp, pl = t / cpp;
+    const int img = g_img[g], x1 = g_x1[g], y1 = g_y1[g], gw = g_w[g];
+    for (int i = t; i < 4 * C; i += 256) stat[i] = stat_g[(size_t)g * 4 * C + i];
+    __syncthreads();
+    const T* pbase = prior + (size_t)g * S * S * C + (size_t)ch * N;
+    const T* fbase = feat + (size_t)img * S * FW * C + (size_t)ch * N;
+    T* obase = out + (size_t)g * S * S * 2 * C;
+    const int c0 = ch * N;
+    const int per = (S * S + slices - 1) / slices, p_end = min(S * S, (sl + 1) * per);
+    for (int p = sl * per + pl; p < p_end; p += plane) {
+        const int y = p / S, x = p - y * S;
+        u32x4 oa = {0u, 0u, 0u, 0u}, ob = {0u, 0u, 0u, 0u};
+        if (x < gw) {
+            float a[N], o[N];
+            Vec<T>::unpack(ldg16(pbase + ((size_t)y * S + (y1 + x)) * C), a);
+            ob = ldg16(fbase + ((size_t)y * FW + (x1 + x)) * C);
+#pragma unroll
+            for (int j = 0; j < N; ++j) {
+                const int c = c0 + j;
+                o[j] = (a[j] - stat[c]) / stat[C + c] * stat[3 * C + c] + stat[2 * C + c];
+            }
+            oa = Vec<T>::pack(o);
+        }
+        stg16(obase + (size_t)p * 2 * C + c0, oa);
+        stg16(obase + (size_t)p * 2 * C + C + c0, ob);
+    }
+}
+
+extern "C" int mnet_adain_crop_concat_split(const void* prior, const void* feat, void* out, int32_t dtype, int32_t G,
+                                            int32_t S, int32_t C, int32_t feat_w, const int32_t* g_img,
+                                            const int32_t* g_x1, const int32_t* g_y1, const int32_t* g_w,
+                                            const float* gamma, const float* beta, float eps, float* scale, float* shift,
+                                            double* partial, float* stat, int32_t slices, void* stream) {
+    MNET_CHECK_ARG(prior && feat && out && g_img && g_x1 && g_y1 && g_w && partial && stat, "adain_split: null pointer");
+    MNET_CHECK_ARG(G > 0 && G <= 65535 && S > 0 && C > 0 && feat_w >= S && slices > 0 && slices <= 1024, "adain_split: bad geometry");
+    MNET_CHECK_ARG(dtype == MNET_F32 || dtype == MNET_F16, "adain_split: bad dtype");
+    MNET_CHECK_ARG((gamma != nullptr) == (beta != nullptr) && (gamma != nullptr) == (scale != nullptr) && (gamma != nullptr) == (shift != nullptr),
+                   "adain_split: gamma, beta, scale, shift go together");
+    const int N = dtype == MNET_F16 ? 8 : 4;
+    MNET_CHECK_ALIGN(C % N == 0 && 256 % (C / N) == 0 && C % 32 == 0 && aligned16(prior) && aligned16(feat) && aligned16(out),
+                     "adain_split: C=%d unsupported or unaligned", C);
+    const size_t lds1 = (size_t)256 * N * 4 * sizeof(double);
+    const size_t lds2 = (size_t)4 * C * sizeof(double) + (size_t)(2 * C / 32) * 2 * sizeof(float);
+    const size_t lds3 = (size_t)4 * C * sizeof(float);
+    MNET_CHECK_ARG(lds2 <= 65536 && lds3 <= 65536, "adain_split: C=%d too large", C);
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    static thread_local bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(adain_stats_kernel<f16>), hipFuncAttributeMaxDynamicSharedMemorySize, 256 * 8 * 4 * 8);
+        attr_set = true;
+    }
+    if (dtype == MNET_F16) hipLaunchKernelGGL(adain_stats_kernel<f16>, dim3(slices, G), dim3(256), lds1, st, (const f16*)prior, (const f16*)feat, S, C, feat_w, g_img, g_x1, g_y1, g_w, partial, slices);
+    else hipLaunchKernelGGL(adain_stats_kernel<float>, dim3(slices, G), dim3(256), lds1, st, (const float*)prior, (const float*)feat, S, C, feat_w, g_img, g_x1, g_y1, g_w, partial, slices);
+    MNET_LAUNCH_CHECK("adain_stats");
+    hipLaunchKernelGGL(adain_finalize_kernel, dim3(G), dim3(256), lds2, st, partial, slices, S, C, g_w, stat, gamma, beta, eps, scale, shift);
+    MNET_LAUNCH_CHECK("adain_finalize");
+    if (dtype == MNET_F16) hipLaunchKernelGGL(adain_apply_kernel<f16>, dim3(slices, G), dim3(256), lds3, st, (const f16*)prior, (const f16*)feat, (f16*)out, S, C, feat_w, g_img, g_x1, g_y1, g_w, stat, slices);
+    else hipLaunchKernelGGL(adain_apply_kernel<float>, dim3(slices, G), dim3(256), lds3, st, (const float*)prior, (const float*)feat, (float*)out, S, C, feat_w, g_img, g_x1, g_y1, g_w, stat, slices);
+    MNET_LAUNCH_CHECK("adain_apply");
+    return MNET_OK;
 }
 
 // ============================================================================ ordered glyph scatter
@@ -505,24 +683,38 @@ extern "C" int mnet_pixelnorm(const float* x, float* y, int32_t N_, int32_t D, v
 
 // ============================================================================ demodulation
 // block per sample n: s^2 staged in LDS, thread o walks i with coalesced reads of wsq_t[i][o]
+// grid (cout/64, styles): a workgroup owns 64 output channels of one style; its 4 waves each sum one quarter of cin (the loop
+// is a chain of exposed load latencies — 16 loads are kept in flight per lane), folded in fixed order through LDS.
 __global__ void __launch_bounds__(256) demod_kernel(const float* __restrict__ style, const float* __restrict__ wsq_t,
                                                     float* __restrict__ demod, int cin, int cout) {
     extern __shared__ __attribute__((aligned(16))) unsigned char dyn[];
-    float* s2 = reinterpret_cast<float*>(dyn);
-    const int n = blockIdx.x;
+    float* s2 = reinterpret_cast<float*>(dyn);                  // [cin] squared style
+    __shared__ float part[4][64];
+    const int n = blockIdx.y, lane = threadIdx.x & 63, q = threadIdx.x >> 6;
+    const int o = blockIdx.x * 64 + lane, oc = min(o, cout - 1);
     for (int i = threadIdx.x; i < cin; i += 256) { const float s = style[(size_t)n * cin + i]; s2[i] = s * s; }
     __syncthreads();
-    for (int o = threadIdx.x; o < cout; o += 256) {
-        float acc = 0.f;
-        for (int i = 0; i < cin; ++i) acc = fmaf(s2[i], wsq_t[(size_t)i * cout + o], acc);
-        demod[(size_t)n * cout + o] = rsqrtf(acc + 1e-8f);
+    const int per = (cin + 3) >> 2, i0 = q * per, i1 = min(cin, i0 + per);
+    const float* wp = wsq_t + oc;
+    float acc = 0.f;
+    int i = i0;
+    for (; i + 16 <= i1; i += 16) {
+        float w[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) w[u] = wp[(size_t)(i + u) * cout];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) acc = fmaf(s2[i + u], w[u], acc);
     }
+    for (; i < i1; ++i) acc = fmaf(s2[i], wp[(size_t)i * cout], acc);
+    part[q][lane] = acc;
+    __syncthreads();
+    if (q == 0 && o < cout) demod[(size_t)n * cout + o] = rsqrtf(((part[0][lane] + part[1][lane]) + (part[2][lane] + part[3][lane])) + 1e-8f);
 }
 
 extern "C" int mnet_demod(const float* style, const float* wsq_t, float* demod, int32_t N_, int32_t cin,
                           int32_t cout, void* stream) {
-    MNET_CHECK_ARG(style && wsq_t && demod && N_ > 0 && cin > 0 && cout > 0, "demod: bad args");
-    hipLaunchKernelGGL(demod_kernel, dim3(N_), dim3(256), (size_t)cin * sizeof(float), reinterpret_cast<hipStream_t>(stream),
+    MNET_CHECK_ARG(style && wsq_t && demod && N_ > 0 && cin > 0 && cout > 0 && N_ <= 65535, "demod: bad args");
+    hipLaunchKernelGGL(demod_kernel, dim3((cout + 63) / 64, N_), dim3(256), (size_t)cin * sizeof(float), reinterpret_cast<hipStream_t>(stream),
                        style, wsq_t, demod, cin, cout);
     MNET_LAUNCH_CHECK("demod");
     return MNET_OK;

@@ -23,3 +23,8 @@ int launch_conv_dma(const ConvArgs& a, hipStream_t st, int cfg);   // cfg < 0: c
 // conv_strip_dma.hip (3x3 / stride 1: one activation strip per filter row)
 int conv_strip_pick(const ConvArgs& a, int dtype, bool explicit_request);   // strip configuration id, or -1 when not eligible / not preferred
 int launch_conv_strip(const ConvArgs& a, hipStream_t st, int cfg);
+
+// conv_skinny.hip (fp32 1x1 over <= 512 pixels: the TextViT linears of a small batch; bit-identical to the general kernel)
+bool conv_skinny_eligible(const ConvArgs& a, int dtype);
+int launch_conv_skinny(const ConvArgs& a, hipStream_t st);
+int launch_conv_skinny_splitk(const ConvArgs& a, int dtype, int ksplit, float* ws, hipStream_t st);   // filter == stride, split-K + ordered reduce

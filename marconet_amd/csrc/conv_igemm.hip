@@ -336,7 +336,7 @@ extern "C" double mnet_conv2d_flops(const mnet_conv_desc* d) {
 static int conv_prepare(const mnet_conv_desc* d, int32_t algo, ConvArgs& a) {
     a.one_tile_per_wg = (algo & MNET_CONV_ALGO_FLAG_ONE_TILE) ? 1 : 0;
     algo &= ~MNET_CONV_ALGO_FLAG_ONE_TILE;
-    MNET_CHECK_ARG((algo >= 0 && algo <= 2) || (algo >= MNET_CONV_ALGO_DMA_CFG0 && algo < MNET_CONV_ALGO_DMA_CFG0 + 16) ||
+    MNET_CHECK_ARG((algo >= 0 && algo <= 3) || (algo >= MNET_CONV_ALGO_DMA_CFG0 && algo < MNET_CONV_ALGO_DMA_CFG0 + 16) ||
                    (algo >= MNET_CONV_ALGO_STRIP_CFG0 && algo < MNET_CONV_ALGO_STRIP_CFG0 + 3), "conv: bad algo %d", algo);
     MNET_CHECK_ARG(d != nullptr, "conv: null descriptor");
     MNET_CHECK_ARG(d->dtype == MNET_F32 || d->dtype == MNET_F16, "conv: bad dtype %d", d->dtype);
@@ -375,7 +375,7 @@ static int conv_prepare(const mnet_conv_desc* d, int32_t algo, ConvArgs& a) {
     return MNET_OK;
 }
 
-// resolves `algo` to the kernel that runs: MNET_CONV_ALGO_REG_STAGED, MNET_CONV_ALGO_DMA_CFG0 + id or
+// resolves `algo` to the kernel that runs: MNET_CONV_ALGO_REG_STAGED, MNET_CONV_ALGO_SKINNY, MNET_CONV_ALGO_DMA_CFG0 + id or
 // MNET_CONV_ALGO_STRIP_CFG0 + id (negative: error)
 static int conv_resolve(const mnet_conv_desc* d, int32_t algo, const ConvArgs& a) {
     algo &= ~MNET_CONV_ALGO_FLAG_ONE_TILE;
@@ -388,6 +388,13 @@ static int conv_resolve(const mnet_conv_desc* d, int32_t algo, const ConvArgs& a
                              algo - MNET_CONV_ALGO_STRIP_CFG0, strip);
         return algo;
     }
+    if (algo == MNET_CONV_ALGO_SKINNY) {
+        if (!conv_skinny_eligible(a, d->dtype))
+            return mnet_fail(MNET_E_ARG, "conv: the skinny kernel needs fp32, 1x1 / stride 1 / no padding, one source, cin %% 16 == 0, "
+                                         "no input transform and <= 512 pixels");
+        return algo;
+    }
+    if (algo == MNET_CONV_ALGO_AUTO && conv_skinny_eligible(a, d->dtype)) return MNET_CONV_ALGO_SKINNY;
     if (algo >= MNET_CONV_ALGO_LDS_DMA && !dma_ok)
         return mnet_fail(MNET_E_ARG, "conv: LDS-DMA algo needs f16, cin %% 64 == 0, cout >= 64, cout %% 8 == 0 and no input transform");
     if (algo >= MNET_CONV_ALGO_DMA_CFG0) return algo;
@@ -412,7 +419,15 @@ extern "C" int mnet_conv2d_nhwc_ex(const mnet_conv_desc* d, int32_t algo, void* 
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     if (k >= MNET_CONV_ALGO_STRIP_CFG0) return launch_conv_strip(a, st, k - MNET_CONV_ALGO_STRIP_CFG0);
     if (k >= MNET_CONV_ALGO_DMA_CFG0) return launch_conv_dma(a, st, k - MNET_CONV_ALGO_DMA_CFG0);
+    if (k == MNET_CONV_ALGO_SKINNY) return launch_conv_skinny(a, st);
     return d->dtype == MNET_F16 ? launch_dtype<f16>(a, st) : launch_dtype<float>(a, st);
+}
+
+extern "C" int mnet_conv2d_splitk(const mnet_conv_desc* d, int32_t ksplit, float* workspace, void* stream) {
+    ConvArgs a;
+    const int rc = conv_prepare(d, MNET_CONV_ALGO_AUTO, a);
+    if (rc != MNET_OK) return rc;
+    return launch_conv_skinny_splitk(a, d->dtype, ksplit, workspace, reinterpret_cast<hipStream_t>(stream));
 }
 
 extern "C" int mnet_conv2d_nhwc(const mnet_conv_desc* d, void* stream) {

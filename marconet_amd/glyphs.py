@@ -50,3 +50,11 @@ class GlyphTables:
         self.G = int(g_img.shape[0])
         t = lambda v: torch.from_numpy(np.ascontiguousarray(v, dtype=np.int32)).to(device)
         self.g_img, self.g_x1, self.g_y1, self.g_w, self.g_start = t(g_img), t(x1), t(y1), t(gw), t(g_start)
+
+    def copy_into(self, static):
+        """overwrite the (same-shaped) device tables of ``static`` with these — the HIP-graph path keeps its tables at fixed
+        addresses and refreshes their contents before every replay"""
+        if static.G != self.G or static.g_start.shape != self.g_start.shape:
+            raise ValueError("glyph tables of a different shape (%d vs %d glyphs)" % (self.G, static.G))
+        for name in ("g_img", "g_x1", "g_y1", "g_w", "g_start"):
+            getattr(static, name).copy_(getattr(self, name), non_blocking=True)

@@ -464,10 +464,11 @@ class TSPSRNet(nn.Module, _Precision):
             p64 = self._gather_priors(priors64, dtype, 256, 64) if sum(counts64) else None
             return self.forward_packed(lq, p64, p32, counts64, counts32, locs, nchw_out=True)
 
-    def forward_packed(self, lq, p64, p32, counts64, counts32, locs, nchw_out=False):
+    def forward_packed(self, lq, p64, p32, counts64, counts32, locs, nchw_out=False, tables=None):
         """batched entry: ``p64`` NHWC [ΣN,64,64,256] / ``p32`` NHWC [ΣN,32,32,512] hold the glyph priors of all
         images back to back (``counts*[b]`` glyphs for image b).  Returns NHWC [B,128,2048,8] (RGB in channels 0-2), or —
-        ``nchw_out`` — the reference's fp32 NCHW [B,3,128,2048] written by the last conv itself."""
+        ``nchw_out`` — the reference's fp32 NCHW [B,3,128,2048] written by the last conv itself.  ``tables``: prebuilt
+        (GlyphTables@32, GlyphTables@64) instead of ``locs`` (the HIP-graph path keeps them at fixed device addresses)."""
         with torch.no_grad():
             pk = self._cache.get(self, self.precision, self._build)
             dtype = torch_dtype(self.precision)
@@ -481,9 +482,9 @@ class TSPSRNet(nn.Module, _Precision):
 
             # glyph windows: ONE device→host copy of locs, integer tables back
             n32, n64 = sum(counts32), sum(counts64)
-            locs_host = locs.detach().float().cpu().numpy() if (n32 + n64) else None
+            locs_host = locs.detach().float().cpu().numpy() if (n32 + n64) and tables is None else None
             if n32:
-                tab32 = GlyphTables(locs_host, counts32, s32.shape[2], 16, lq.device)
+                tab32 = tables[0] if tables is not None else GlyphTables(locs_host, counts32, s32.shape[2], 16, lq.device)
                 p32 = self._two(pk, "conv_32_to256", p32)                                        # :424
                 s32 = self._prior_transform(pk, "32", s32, p32, tab32)                           # :425-449
                 del p32
@@ -494,7 +495,7 @@ class TSPSRNet(nn.Module, _Precision):
             s64 = self._c(pk, "conv_up.4", h)
             del h
             if n64:
-                tab64 = GlyphTables(locs_host, counts64, s64.shape[2], 32, lq.device)
+                tab64 = tables[1] if tables is not None else GlyphTables(locs_host, counts64, s64.shape[2], 32, lq.device)
                 s64 = self._prior_transform(pk, "64", s64, p64, tab64)                           # :455-482
                 del p64
 

@@ -4,6 +4,7 @@
 Activations are NHWC torch tensors of dtype float32 or float16, shape [N,H,W,C].
 """
 import ctypes
+import os
 
 import torch
 
@@ -63,8 +64,9 @@ stats = _Stats()
 
 def conv2d(x0, wgt, cout, kh=1, kw=1, stride=(1, 1), pad=(0, 0), x1=None, in_scale=None, in_shift=None,
            in_swish=False, valid_w=None, out_scale=None, bias=None, residual=None, res_mod=0, act=ACT_NONE,
-           post_scale=None, out=None, algo=0):
-    """mnet_conv2d_nhwc(_ex).  x0 [N,H,W,C0] (+ optional x1 [N,H,W,C1]); wgt packed [cout,kh,kw,C0+C1] same dtype."""
+           post_scale=None, out=None, algo=0, splitk=0):
+    """mnet_conv2d_nhwc(_ex).  x0 [N,H,W,C0] (+ optional x1 [N,H,W,C1]); wgt packed [cout,kh,kw,C0+C1] same dtype.
+    ``splitk`` > 0: mnet_conv2d_splitk with that many K-slices (fp32 filter == stride convs over <= 512 output pixels)."""
     lib = _lib.load()
     _need_cuda(x0, x1, wgt, in_scale, in_shift, valid_w, out_scale, bias, residual, post_scale, out)
     n, h, w, c0 = x0.shape
@@ -104,6 +106,13 @@ def conv2d(x0, wgt, cout, kh=1, kw=1, stride=(1, 1), pad=(0, 0), x1=None, in_sca
         raise TypeError("conv2d: valid_w must be int32")
     if residual is not None and residual.dtype != x0.dtype:
         raise TypeError("conv2d: residual dtype mismatch")
+    if splitk:
+        ws = torch.empty((splitk * n * ho * wo * cout,), dtype=torch.float32, device=x0.device)
+        if stats.enabled:
+            stats.conv_flops += lib.mnet_conv2d_flops(ctypes.byref(d))
+            stats.conv_launches += 1
+        _lib.check(lib.mnet_conv2d_splitk(ctypes.byref(d), splitk, _p(ws), _stream()), "mnet_conv2d_splitk")
+        return out
     if stats.enabled:
         fl = lib.mnet_conv2d_flops(ctypes.byref(d))
         stats.conv_flops += fl
@@ -177,7 +186,7 @@ def groupnorm_affine(x, gamma, beta, eps=1e-6, valid_w=None):
     lib = _lib.load()
     _need_cuda(x, gamma, beta, valid_w)
     n, h, w, c = x.shape
-    slices = max(1, min(128, (h * w) // 2048))
+    slices = max(1, min(128, (h * w) // 512))      # a function of the map size only: the fp64 fold order never depends on the batch
     partial = torch.empty((n * slices * (c // 32) * 2,), dtype=torch.float64, device=x.device)
     scale = torch.empty((n, c), dtype=torch.float32, device=x.device)
     shift = torch.empty((n, c), dtype=torch.float32, device=x.device)
@@ -199,8 +208,13 @@ def adain_crop_concat(prior, feat, g_img, g_x1, g_y1, g_w):
     return out
 
 
-def adain_crop_concat_gn(prior, feat, g_img, g_x1, g_y1, g_w, gamma, beta, eps=1e-6):
-    """adain_crop_concat + the GroupNorm affine of its output (closed form from the AdaIN statistics) → (out, scale, shift)"""
+ADAIN_SPLIT_BELOW = 256      # glyphs per launch below which the three-launch (16 workgroups per glyph) form is used
+_ADAIN_SPLIT = {"0": False, "1": True}.get(os.environ.get("MNET_ADAIN_SPLIT", ""))     # A/B knob
+
+
+def adain_crop_concat_gn(prior, feat, g_img, g_x1, g_y1, g_w, gamma, beta, eps=1e-6, split=None):
+    """adain_crop_concat + the GroupNorm affine of its output (closed form from the AdaIN statistics) → (out, scale, shift).
+    ``split``: None = by glyph count; the two forms agree up to the association of the fp64 statistic sums."""
     lib = _lib.load()
     _need_cuda(prior, feat, g_img, g_x1, g_y1, g_w, gamma, beta)
     G, S, S2, C = prior.shape
@@ -210,6 +224,16 @@ def adain_crop_concat_gn(prior, feat, g_img, g_x1, g_y1, g_w, gamma, beta, eps=1
     out = torch.empty((G, S, S, 2 * C), dtype=prior.dtype, device=prior.device)
     scale = torch.empty((G, 2 * C), dtype=torch.float32, device=prior.device)
     shift = torch.empty((G, 2 * C), dtype=torch.float32, device=prior.device)
+    if split is None:
+        split = _ADAIN_SPLIT if _ADAIN_SPLIT is not None else G < ADAIN_SPLIT_BELOW
+    if split:       # few glyphs (a strip at a time): spread each glyph over 16 workgroups instead of one
+        slices = 16
+        partial = torch.empty((G * slices * C * 4,), dtype=torch.float64, device=prior.device)
+        stat = torch.empty((G, 4, C), dtype=torch.float32, device=prior.device)
+        _lib.check(lib.mnet_adain_crop_concat_split(_p(prior), _p(feat), _p(out), _dt(prior), G, S, C, FW, _p(g_img), _p(g_x1),
+                                                    _p(g_y1), _p(g_w), _p(gamma), _p(beta), eps, _p(scale), _p(shift),
+                                                    _p(partial), _p(stat), slices, _stream()), "mnet_adain_crop_concat_split")
+        return out, scale, shift
     _lib.check(lib.mnet_adain_crop_concat_gn(_p(prior), _p(feat), _p(out), _dt(prior), G, S, C, FW, _p(g_img), _p(g_x1),
                                              _p(g_y1), _p(g_w), _p(gamma), _p(beta), eps, _p(scale), _p(shift), _stream()),
                "mnet_adain_crop_concat_gn")

@@ -10,6 +10,8 @@ import torch.nn as nn
 from . import ops
 from .packing import PackCache, pack_vec, posemb_sincos_1x64
 
+EMBED_KSPLIT = 32      # K-slices of the patch embedding at <= 512 tokens (fixed: the fp32 fold order must not depend on the batch)
+
 
 class FeedForward(nn.Module):
     def __init__(self, dim, hidden_dim):
@@ -105,8 +107,10 @@ class TextViT(nn.Module):
         pk = self._cache.get(self, "fp32", self._build)
         B = feat.shape[0]
         # patchify + Linear == 8x8 / stride-8 conv in NHWC ('(p1 p2 c)' is exactly the NHWC window order), + bias + pos-emb
+        # up to 8 strips (512 tokens) the weight stream (64 MiB) is the whole cost: split-K over 32 slices spreads it over the chip
         x = ops.conv2d(feat, pk["embed.w"], 512, 8, 8, (8, 8), (0, 0), bias=pk["embed.b"],
-                       residual=pk["pe"].reshape(1, 1, 64, 512), res_mod=64).reshape(B * 64, 512)
+                       residual=pk["pe"].reshape(1, 1, 64, 512), res_mod=64,
+                       splitk=EMBED_KSPLIT if B * 64 <= 512 else 0).reshape(B * 64, 512)
         x = self._encoder_block(pk["layers.0"], x, B, 64)
         x = self._encoder_block(pk["layers.1"], x, B, 64)
         x_cls = self._encoder_block(pk["cls"], x, B, 64)

@@ -86,12 +86,29 @@ def test_argument_validation_without_device():
     assert lib.mnet_conv2d_plan(ctypes.byref(d2), _lib.ALGO_LDS_DMA) == -1
     d2.c0 = 64; d2.dtype = 0
     assert lib.mnet_conv2d_plan(ctypes.byref(d2), _lib.ALGO_AUTO) == _lib.ALGO_REG_STAGED          # fp32
+    # fp32 1x1 over a few tokens (the TextViT linears of a small batch) → the skinny kernel; above 512 pixels the general one
+    d3 = _lib.ConvDesc()
+    d3.dtype = 0; d3.x0 = 16; d3.wgt = 16; d3.y = 16; d3.n = d3.h = d3.ho = 1; d3.w = d3.wo = 64
+    d3.c0 = 512; d3.cout = 2048; d3.kh = d3.kw = 1; d3.stride_h = d3.stride_w = 1
+    assert lib.mnet_conv2d_plan(ctypes.byref(d3), _lib.ALGO_AUTO) == _lib.ALGO_SKINNY
+    assert lib.mnet_conv2d_plan(ctypes.byref(d3), _lib.ALGO_REG_STAGED) == _lib.ALGO_REG_STAGED
+    d3.w = d3.wo = 4096
+    assert lib.mnet_conv2d_plan(ctypes.byref(d3), _lib.ALGO_AUTO) == _lib.ALGO_REG_STAGED
+    assert lib.mnet_conv2d_plan(ctypes.byref(d3), _lib.ALGO_SKINNY) == -1 and b"skinny" in lib.mnet_last_error()
+    d3.w = 512; d3.h = 8; d3.wo = 64; d3.kh = d3.kw = d3.stride_h = d3.stride_w = 8                # the TextViT patch embedding of one strip
+    assert lib.mnet_conv2d_splitk(ctypes.byref(d3), 32, None, None) == -1                         # no workspace
+    assert lib.mnet_conv2d_splitk(ctypes.byref(d3), 12, 16, None) == -1 and b"multiple of kh" in lib.mnet_last_error()
+    d3.stride_w = 4; d3.wo = 127
+    assert lib.mnet_conv2d_splitk(ctypes.byref(d3), 32, 16, None) == -1 and b"filter == stride" in lib.mnet_last_error()
     # argument checks of the newer entry points (all before any HIP call)
     assert lib.mnet_conv3x3_rgb(16, 1, 1, 8, 8, 32, 16, 16, 4, 16, None, None) == -1 and b"cin" in lib.mnet_last_error()
     assert lib.mnet_conv3x3_rgb(16, 1, 1, 8, 8, 64, 16, 16, 4, None, None, None) == -1            # no output requested
     assert lib.mnet_sr_postprocess(None, 1, 16, 1, 10, 8, None) == -1
     assert lib.mnet_sr_postprocess(16, 1, 16, 1, 10, 2, None) == -1                                # fewer than 3 channels
     assert lib.mnet_adain_crop_concat_gn(16, 16, 16, 1, 1, 32, 256, 512, 16, 16, 16, 16, None, None, 1e-6, None, None, None) == -1
+    assert lib.mnet_adain_crop_concat_split(16, 16, 16, 1, 1, 32, 256, 512, 16, 16, 16, 16, None, None, 1e-6, None, None, None, 16, 16, None) == -1
+    assert lib.mnet_adain_crop_concat_split(16, 16, 16, 1, 1, 32, 256, 512, 16, 16, 16, 16, 16, None, 1e-6, None, None, 16, 16, 16, None) == -1
+    assert b"go together" in lib.mnet_last_error()
 
 
 def test_ops_refuse_cpu_tensors():

@@ -235,9 +235,17 @@ def test_adain_crop_and_scatter(S, dtype):
     # the same launch can also emit the GroupNorm affine of its output (closed form from the AdaIN statistics)
     gamma, beta = _rnd((2 * C,), 29).abs() + 0.5, _rnd((2 * C,), 30) * 0.3
     out2, gsc, gsh = ops.adain_crop_concat_gn(_nhwc(prior, dtype), _nhwc(feat, dtype), g_img.to(DEV), g_x1.to(DEV), g_y1.to(DEV),
-                                              g_w.to(DEV), gamma.to(DEV), beta.to(DEV), 1e-6)
+                                              g_w.to(DEV), gamma.to(DEV), beta.to(DEV), 1e-6, split=False)
+    # ... and the three-launch form used for few glyphs (16 workgroups per glyph): same values up to the association of the fp64
+    # statistic sums, i.e. at most an ulp of the storage type apart
+    out3, gsc3, gsh3 = ops.adain_crop_concat_gn(_nhwc(prior, dtype), _nhwc(feat, dtype), g_img.to(DEV), g_x1.to(DEV), g_y1.to(DEV),
+                                                g_w.to(DEV), gamma.to(DEV), beta.to(DEV), 1e-6, split=True)
     torch.cuda.synchronize()
     assert torch.equal(out2, out)
+    ulp = 1e-3 if dtype == torch.float16 else 2e-7
+    assert torch.allclose(out3.float(), out.float(), rtol=ulp, atol=ulp)
+    assert torch.allclose(gsc3, gsc, rtol=1e-6, atol=1e-7) and torch.allclose(gsh3, gsh, rtol=1e-6, atol=1e-6)
+    print("adain split == fused bit for bit:", bool(torch.equal(out3, out) and torch.equal(gsc3, gsc) and torch.equal(gsh3, gsh)))
     for g, (b, x1, gw) in enumerate(windows):
         y1 = int(g_y1[g])
         cp, cl = prior[g:g + 1, :, :, y1:y1 + gw], feat[b:b + 1, :, :, x1:x1 + gw]
@@ -311,6 +319,9 @@ def test_gan_small_ops():
     wsq_t = ((scale * w) ** 2).sum([2, 3]).t().contiguous()
     d = ops.demod(s.to(DEV), wsq_t.to(DEV))
     _check("demod", d.cpu(), ref, torch.float32, extra=2.0)
+    s2, w2 = _rnd((3, 515), 46) + 1, _rnd((100, 515), 47).abs()          # cin, cout off the 64/16 grid; wsq_t given directly
+    d2 = ops.demod(s2.to(DEV), w2.t().contiguous().to(DEV))
+    _check("demod ragged", d2.cpu(), torch.rsqrt((s2.double() ** 2 @ w2.double().t()) + 1e-8).float(), torch.float32, extra=2.0)
     lg = _rnd((70, 6736), 43)
     lg[5, 100] = lg[5, 200] = 50.0
     assert torch.equal(ops.argmax_rows(lg.to(DEV)).cpu(), lg.argmax(-1))
@@ -565,3 +576,54 @@ def test_conv3x3_rgb_kernel(dtype, shape):
     _check("conv3x3_rgb nhwc %s %s" % (shape, dtype), _nchw(y_nhwc)[:, :3], ref, dtype, extra=2.0)
     assert float(y_nhwc[..., 3:].abs().max()) == 0.0
     assert torch.equal(y_nchw.cpu(), _nchw(y_nhwc)[:, :3].contiguous())
+
+
+@pytest.mark.parametrize("case", [(64, 512, 512, 5, True), (64, 2048, 512, 0, True), (64, 512, 6736, 0, False), (100, 512, 2048, 5, False),
+                                  (512, 48, 20, 1, True), (1, 16, 4, 6, False), (130, 272, 36, 4, True)])
+def test_skinny_linear_equals_general_kernel(case):
+    """the fp32 skinny kernel (TextViT linears of a small batch) gives the register-staged kernel's bits — an image's result must
+    not depend on which of the two the batch size selects — and both match torch within the fp32 tolerance"""
+    ops = _ops()
+    from marconet_amd import _lib
+    m, k, cout, act, with_res = case
+    x = _rnd((m, k), 61).to(DEV)
+    wt = _rnd((cout, k), 62, 1.0 / math.sqrt(k)).to(DEV)
+    bias = _rnd((cout,), 63, 0.3).to(DEV)
+    res = _rnd((m, cout), 64).to(DEV) if with_res else None
+    kw = dict(bias=bias, act=act, residual=None if res is None else res.reshape(1, 1, m, cout))
+    y_s = ops.conv2d(x.reshape(1, 1, m, k), wt, cout, algo=_lib.ALGO_SKINNY, **kw)
+    y_g = ops.conv2d(x.reshape(1, 1, m, k), wt, cout, algo=_lib.ALGO_REG_STAGED, **kw)
+    y_a = ops.conv2d(x.reshape(1, 1, m, k), wt, cout, **kw)
+    torch.cuda.synchronize()
+    assert torch.equal(y_s, y_g) and torch.equal(y_a, y_s)
+    ref = x.double() @ wt.double().t() + bias.double()
+    if res is not None:
+        ref = ref + res.double()
+    ref = {0: lambda v: v, 1: torch.relu, 4: torch.tanh, 5: lambda v: F.gelu(v), 6: torch.sigmoid}[act](ref)
+    assert (y_s.reshape(m, cout).double() - ref).abs().max().item() < 2e-4
+
+
+@pytest.mark.parametrize("case", [(1, 8, 512, 512, 8, 512, 32), (3, 8, 64, 32, 8, 20, 8), (2, 4, 40, 16, 4, 36, 4), (5, 1, 7, 64, 1, 128, 2)])
+def test_patchify_conv_splitk(case):
+    """mnet_conv2d_splitk (TextViT patch embedding of a small batch): equals the general kernel up to the association of the fp32
+    sum, is deterministic, and matches torch"""
+    ops = _ops()
+    n, h, w, c, k, cout, ksplit = case
+    x = _rnd((n, c, h, w), 71)
+    wt = _rnd((cout, c, k, k), 72, 1.0 / math.sqrt(c * k * k))
+    bias = _rnd((cout,), 73, 0.3).to(DEV)
+    wo = w // k
+    res = _rnd((1, 1, wo, cout), 74).to(DEV)
+    kw = dict(bias=bias, residual=res, res_mod=wo, act=5)
+    x0 = _nhwc(x, torch.float32)
+    y_s = ops.conv2d(x0, _pack_w(wt, torch.float32), cout, k, k, (k, k), (0, 0), splitk=ksplit, **kw)
+    y_s2 = ops.conv2d(x0, _pack_w(wt, torch.float32), cout, k, k, (k, k), (0, 0), splitk=ksplit, **kw)
+    y_g = ops.conv2d(x0, _pack_w(wt, torch.float32), cout, k, k, (k, k), (0, 0), **kw)
+    torch.cuda.synchronize()
+    assert torch.equal(y_s, y_s2)
+    assert torch.allclose(y_s, y_g, rtol=1e-4, atol=2e-5)          # K up to 32768 fp32 terms, associated differently
+    ref = F.conv2d(x.double(), wt.double(), stride=k) + bias.cpu().double().view(1, -1, 1, 1)
+    ref = ref + res.cpu().double().reshape(wo, cout).t()[None, :, None, :].expand(n, cout, h // k, wo)
+    _check("patchify split-K %s" % (case,), _nchw(y_s), F.gelu(ref).float(), torch.float32)
+    with pytest.raises(RuntimeError):
+        ops.conv2d(x0, _pack_w(wt, torch.float32), cout, k, k, (k, k), (0, 0), splitk=ksplit * 3 + 1, **kw)

@@ -361,3 +361,25 @@ def test_generator_distinct_styles_equal_expanded(nets):
         for u, v in zip(a, b):
             assert torch.equal(u, v)
     nets[1].set_precision("fp32")
+
+
+@pytest.mark.parametrize("output", ["nchw_f32", "u8_bgr"])
+def test_hip_graph_replay_equals_eager(nets, output):
+    """GraphedForward (the whole forward of one batch signature captured in a HIP graph) gives the eager driver's bits, also
+    when replayed on new LQ / labels / locations; a different glyph-count signature is refused"""
+    from marconet_amd.pipeline import GraphedForward, MarconetPipeline
+    pipe = MarconetPipeline(*nets, precision="fp16")
+    try:
+        counts = [5, 0, 3]
+        gf = GraphedForward(pipe, 3, counts, output=output)
+        for seed in (41, 42):
+            lq = synth.make_lq(seed, 3, [512, 512, 300]).to(DEV)
+            labels = [synth.make_labels(seed * 10 + b, n) for b, n in enumerate(counts)]
+            locs = synth.make_locs(counts, [512, 512, 300])
+            want = pipe.forward_batch(lq, labels, locs, output=output)
+            got = gf(lq, labels, locs).clone()
+            assert got.dtype == want.dtype and torch.equal(got, want), seed
+        with pytest.raises(ValueError):
+            gf(lq, [labels[0], labels[2], labels[2]], locs)
+    finally:
+        pipe.set_precision("fp32")
