@@ -155,7 +155,7 @@ def main():
     # launch stream around every conv launch; the kernel each launch resolved to comes from mnet_conv2d_plan)
     KNAME = {1: "conv_igemm_kernel (register-staged)", 3: "conv_skinny_f32_kernel", 16: "conv_dma_kernel<256,256,4,4,2,16>", 17: "conv_dma_kernel<256,128,4,2,3,16>",
              18: "conv_dma_kernel<128,256,2,4,3,16>", 19: "conv_dma_kernel<64,256,1,8,3,16>", 20: "conv_dma_kernel<128,512,2,8,2,16>",
-             21: "conv_dma_kernel<64,512,1,8,2,16>", 22: "conv_dma_kernel<256,256,2,4,2,16>",
+             21: "conv_dma_kernel<64,512,1,8,2,16>", 22: "conv_dma_kernel<256,256,2,4,2,16>", 26: "conv_dma_kernel<128,128,2,4,4,16>",
              32: "conv_strip_kernel<256,256,4,4>", 33: "conv_strip_kernel<64,512,1,8>", 34: "conv_strip_kernel<128,256,2,4>"}
     per = {}
     for s_, e_, fl, dt_, kid in ops.stats.events:

@@ -103,6 +103,7 @@ int mnet_conv2d_nhwc(const mnet_conv_desc* d, void* stream);
  *      5: 64x512 8w 2st     6: 256x256 8w 2st (128x64 per wave)      — all on v_mfma_f32_16x16x32_f16 walking k in the
  *      same order (64-channel slice outer, filter tap inner): the same bits for every launch size (batch-invariant);
  *      the register-staged kernel walks k tap-outer (same products, fp32 partial sums associated differently)
+ *   id 10: 128x128 8w 4st (3 slabs in flight: a lone small tile per CU exposes the load latency) — AUTO's choice when ids 1 / 2 would give fewer than 200 workgroups (one strip at a time)
  *   id 7/8/9: ids 0/4/5 on v_mfma_f32_32x32x16_f16 (experimental)
  *   id 11-15: diagnostic builds used by tools/wg_timeline.py and tools/conv_bench.py; they produce WRONG results */
 enum { MNET_CONV_ALGO_AUTO = 0, MNET_CONV_ALGO_REG_STAGED = 1, MNET_CONV_ALGO_LDS_DMA = 2,

@@ -35,7 +35,7 @@ __global__ void __launch_bounds__(WC * WP * 64, WC * WP / 4) conv_dma_kernel(con
     constexpr unsigned OOB = 0x80000000u;                // beyond every num_records used below
     static_assert(NW == 8 || NW == 16, "8 or 16 waves");
     static_assert(WJ >= 1 && XJ >= 1 && WJ * 8 * NW == BC && XJ * 8 * NW == BP, "tile / wave-count mismatch");
-    static_assert(STAGES == 2 || (STAGES == 3 && (NDMA == 6 || NDMA == 5)), "vmcnt immediates below assume 5 or 6 DMAs per slab");
+    static_assert(STAGES == 2 || ((STAGES == 3 || STAGES == 4) && NDMA >= 4 && NDMA <= 6), "vmcnt immediates below cover 4-6 DMAs per slab, up to 3 slabs in flight");
     static_assert((BC / WC) % 64 == 0 && (BP / WP) % 32 == 0, "the channel permutation works on 64-channel blocks of a wave tile");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 
@@ -218,6 +218,12 @@ __global__ void __launch_bounds__(WC * WP * 64, WC * WP / 4) conv_dma_kernel(con
         }
     };
 
+    // wait until at most `keep` (1 or 2) of this wave's slabs are still in flight: vmcnt(keep * NDMA), an immediate
+    auto wait_keep = [&](int keep) {
+        if (keep >= 2) { if constexpr (NDMA == 6) VMCNT(12); else if constexpr (NDMA == 5) VMCNT(10); else VMCNT(8); }
+        else { if constexpr (NDMA == 6) VMCNT(6); else if constexpr (NDMA == 5) VMCNT(5); else VMCNT(4); }
+    };
+
     // ---- prime the ring (STAGES-1 slabs ahead), then walk this workgroup's tiles
     setup(i_v);
     int inflight = 0;
@@ -248,7 +254,7 @@ __global__ void __launch_bounds__(WC * WP * 64, WC * WP / 4) conv_dma_kernel(con
         const int hot = nk - (STAGES - 1) > 0 ? nk - (STAGES - 1) : 0;
         for (int kt = 0; kt < hot; ++kt) {
             // the oldest slab in flight must have landed (this wave's share; the barrier extends it to everyone's)
-            if (STAGES == 3 && !drain) { if constexpr (NDMA == 6) VMCNT(6); else VMCNT(5); }
+            if (STAGES > 2 && !drain) wait_keep(STAGES - 2);
             else VMCNT(0);
             drain = false;
             __builtin_amdgcn_s_barrier();                // ... and every wave is done reading the stage refilled next
@@ -261,7 +267,7 @@ __global__ void __launch_bounds__(WC * WP * 64, WC * WP / 4) conv_dma_kernel(con
         // tail iterations: the slab issued belongs to this workgroup's NEXT tile (set-up + first-slab latency overlap the
         // last multiplies and the epilogue of this one)
         for (int kt = hot; kt < nk; ++kt) {
-            if (STAGES == 3 && inflight == 2 && !drain) { if constexpr (NDMA == 6) VMCNT(6); else VMCNT(5); }
+            if (STAGES > 2 && inflight >= 2 && !drain) wait_keep(inflight - 1);
             else VMCNT(0);
             drain = false;
             __builtin_amdgcn_s_barrier();
@@ -335,6 +341,7 @@ static int launch_dma_id(int id, const ConvArgs& a, hipStream_t st) {
         case 7: return launch_dma_cfg<256, 256, 4, 4, 2, 32>(a, st);
         case 8: return launch_dma_cfg<128, 512, 2, 8, 2, 32>(a, st);
         case 9: return launch_dma_cfg<64, 512, 1, 8, 2, 32>(a, st);
+        case 10: return launch_dma_cfg<128, 128, 2, 4, 4>(a, st);          // small launches: twice the workgroups of ids 1 / 2, 3 slabs in flight
         case 11: return launch_dma_cfg<256, 256, 4, 4, 2, 16, 4>(a, st);  // DIAGNOSTIC: all tiles store over tile 0; stamps after tile 0
         case 12: return launch_dma_cfg<256, 256, 4, 4, 2, 16, 5>(a, st);  // DIAGNOSTIC: no output stores; stamps after tile 0
         case 13: return launch_dma_cfg<256, 256, 4, 4, 2, 16, 3>(a, st);  // DIAGNOSTIC: per-tile time stamps written over the output
@@ -347,8 +354,11 @@ static int launch_dma_id(int id, const ConvArgs& a, hipStream_t st) {
 int conv_dma_pick(const ConvArgs& a) {
     const bool big = a.npix >= 256 * 256;
     static const int env_big256 = [] { const char* e = getenv("MNET_DMA_CFG_BIG256"); return e ? atoi(e) : 0; }();   // A/B knob
-    if (a.cout >= 256) return big ? env_big256 : 1;
-    if (a.cout >= 128) return big ? 4 : 2;
+    // a launch that would leave a quarter or more of the CUs without a tile (a strip at a time: 4096-16384 pixels) takes the
+    // 128x128 tile instead: twice the workgroups (same k order, same bits)
+    const long long t128 = (a.npix + 127) / 128, t256 = (a.npix + 255) / 256;
+    if (a.cout >= 256) return big ? env_big256 : (t128 * ((a.cout + 255) / 256) < 200 ? 10 : 1);
+    if (a.cout >= 128) return big ? 4 : (t256 * ((a.cout + 127) / 128) < 200 ? 10 : 2);
     return big ? 5 : 3;
 }
 

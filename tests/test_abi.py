@@ -80,7 +80,10 @@ def test_argument_validation_without_device():
     d2.cout = 128
     assert lib.mnet_conv2d_plan(ctypes.byref(d2), _lib.ALGO_AUTO) == _lib.ALGO_DMA_CFG0 + 4        # 128x512 tile
     d2.n = 4                                                                                       # 4096 pixels: small-launch tile
+    assert lib.mnet_conv2d_plan(ctypes.byref(d2), _lib.ALGO_AUTO) == _lib.ALGO_DMA_CFG0 + 10       # 16 tiles of 128x256 → 128x128 tiles
+    d2.n = 56                                                                                      # 57344 pixels: 224 tiles of 128x256
     assert lib.mnet_conv2d_plan(ctypes.byref(d2), _lib.ALGO_AUTO) == _lib.ALGO_DMA_CFG0 + 2
+    d2.n = 4
     d2.c0 = 32
     assert lib.mnet_conv2d_plan(ctypes.byref(d2), _lib.ALGO_AUTO) == _lib.ALGO_REG_STAGED          # cin % 64 != 0
     assert lib.mnet_conv2d_plan(ctypes.byref(d2), _lib.ALGO_LDS_DMA) == -1

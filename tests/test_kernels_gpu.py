@@ -407,7 +407,7 @@ def test_conv_lds_dma_kernel(case):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("cfg", [0, 1, 2, 3, 4, 5, 6, 7, 8, 9])
+@pytest.mark.parametrize("cfg", [0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10])
 @pytest.mark.parametrize("shape", [(3, 40, 52, 64, 64, 200, 3), (700, 4, 4, 128, 0, 72, 3), (2, 9, 300, 192, 0, 320, 1)])
 def test_conv_lds_dma_every_tile_config(cfg, shape):
     """every LDS-DMA tile configuration, pinned explicitly, is bit-identical to the register-staged kernel on shapes with
