@@ -190,3 +190,41 @@ def test_glyph_tables_vectorised_equals_scalar_window():
         GlyphTables(np.array([[1.2, 0.0]], dtype=np.float32), [1], 512, 16, "cpu")      # centre beyond the map → empty window
     with pytest.raises(IndexError):
         GlyphTables(np.zeros((1, 4), dtype=np.float32), [3], 512, 16, "cpu")
+
+
+def test_graph_path_host_pieces():
+    """host-side parts of pipeline.GraphedForward that need no GPU: static glyph tables are refreshed in place (same storage,
+    new contents), a different glyph signature is refused, labels are validated before anything is enqueued"""
+    import numpy as np
+    import pytest
+    import torch
+    from marconet_amd import networks
+    from marconet_amd.glyphs import GlyphTables
+    from marconet_amd.pipeline import MarconetPipeline
+    counts = [3, 0, 2]
+    static = GlyphTables(np.full((3, 6), 0.5, np.float32), counts, 512, 16, "cpu")
+    ptrs = [getattr(static, n).data_ptr() for n in ("g_img", "g_x1", "g_y1", "g_w", "g_start")]
+    locs = np.random.default_rng(3).random((3, 6)).astype(np.float32)
+    fresh = GlyphTables(locs, counts, 512, 16, "cpu")
+    fresh.copy_into(static)
+    assert [getattr(static, n).data_ptr() for n in ("g_img", "g_x1", "g_y1", "g_w", "g_start")] == ptrs
+    assert all(torch.equal(getattr(static, n), getattr(fresh, n)) for n in ("g_img", "g_x1", "g_y1", "g_w", "g_start"))
+    with pytest.raises(ValueError):
+        GlyphTables(locs, [3, 1, 2], 512, 16, "cpu").copy_into(static)
+    pipe = MarconetPipeline(networks.TextContextEncoderV2(), networks.TSPGAN(), networks.TSPSRNet())
+    lab, img_of = pipe._host_prep([torch.tensor([5, 6, 7]), torch.zeros(0, dtype=torch.long), torch.tensor([1, 2])], counts, "cpu")
+    assert lab.shape == (5, 1) and img_of.tolist() == [0, 0, 0, 2, 2]
+    assert pipe._host_prep([torch.zeros(0, dtype=torch.long)], [0], "cpu") == (None, None)
+    with pytest.raises(RuntimeError):
+        pipe._host_prep([torch.tensor([6736])], [1], "cpu")
+
+
+def test_header_is_plain_c():
+    """include/marconet_hip.h must be consumable by a C host (cgo / JNI / N-API style bindings): C99, no HIP headers needed"""
+    import subprocess
+    import tempfile
+    with tempfile.TemporaryDirectory() as td:
+        src = os.path.join(td, "use.c")
+        with open(src, "w") as f:
+            f.write('#include "marconet_hip.h"\nint main(void) { mnet_conv_desc d; (void)d; return mnet_abi_version != 0 ? 0 : 1; }\n')
+        subprocess.check_call(["gcc", "-std=c99", "-pedantic", "-Werror", "-fsyntax-only", "-I", os.path.join(ROOT, "include"), src])
