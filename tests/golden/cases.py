@@ -23,6 +23,10 @@ SR_CASES = {
     "grid": (21, [512, 300], [5, 15], None),
     # clipped at both borders, heavy overlap (later glyph wins), a single-glyph image
     "edges": (22, [512, 200], [6, 1], [[5 / 512, 16 / 512, 40 / 512, 0.5, 500 / 512, 511 / 512], [0.31]]),
+    # the configuration the headline metric is quoted on, per image: a full-width strip with the maximum of 16 glyphs
+    "full16": (23, [512], [16], None),
+    # narrowest strip of BASELINE configs[4] (128 px of content in the 512-px canvas), glyph windows 32 px apart
+    "narrow128": (24, [128], [4], None),
 }
 
 
