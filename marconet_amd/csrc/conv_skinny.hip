@@ -11,6 +11,7 @@
 // k grouping (k-steps of 16; lane group g holds k = 4g..4g+3 of the step, MFMA j consumes component j — see Mma<float> in
 // conv_igemm.hip), one accumulator, the same epilogue order.  So an image's result does not depend on which of the two
 // kernels the batch size selects.
+#include <cstdlib>
 #include "common.h"
 #include "conv_args.h"
 
@@ -116,8 +117,9 @@ __global__ void __launch_bounds__(256) skinny_reduce_kernel(const ConvArgs p, co
 }  // namespace
 
 bool conv_skinny_eligible(const ConvArgs& a, int dtype) {
+    static const int max_pix = [] { const char* e = getenv("MNET_SKINNY_MAX_PIX"); return e ? atoi(e) : 512; }();   // A/B knob
     return dtype == MNET_F32 && a.kh == 1 && a.kw == 1 && a.sh == 1 && a.sw == 1 && a.ph == 0 && a.pw == 0 && a.c1 == 0 &&
-           !a.in_scale && !a.valid_w && a.cin % 16 == 0 && a.npix <= 512;
+           !a.in_scale && !a.valid_w && a.cin % 16 == 0 && a.npix <= max_pix;
 }
 
 int launch_conv_skinny(const ConvArgs& a, hipStream_t st) {
