@@ -91,3 +91,114 @@ def posemb_sincos_1x64(device):
 
 def equal_linear_scale(in_channels, lr_mul):
     return (1 / math.sqrt(in_channels)) * lr_mul
+
+
+# ------------------------------------------------------------------------------------------------ offline packed blob
+# SURVEY.md §8(f) NEXT-3: the folded / repacked weights as a file, so that a serving process does not redo the spectral-norm
+# fold and the layout change at start-up and does not need fp32 master weights resident twice while packing.  The file is a
+# safetensors container: one entry per packed tensor, named "<root>[.<holder>]|<precision>|<path in the packed tree>", the tree
+# structure and the non-tensor leaves as JSON metadata, and a SHA-256 of each holder's parameters so that a blob is never
+# attached to different weights.
+PACK_FORMAT = "marconet_amd.packed.v1"
+
+
+def _holders(root):
+    """sub-modules that own a PackCache (ResNet45, TextViT, TextGenerator, TSPSRNet)"""
+    return [(name, m) for name, m in root.named_modules() if isinstance(getattr(m, "_cache", None), PackCache) and hasattr(m, "_build")]
+
+
+def _holder_precision(m):
+    return getattr(m, "precision", "fp32")          # the TextViT has no precision switch: always fp32
+
+
+def _weights_digest(m):
+    import hashlib
+    h = hashlib.sha256()
+    for name, t in list(m.named_parameters()) + list(m.named_buffers()):
+        h.update(name.encode())
+        h.update(t.detach().contiguous().cpu().numpy().tobytes())
+    return h.hexdigest()
+
+
+def _flatten(obj, path, tensors, tree):
+    if torch.is_tensor(obj):
+        tree[path] = {"t": "tensor"}
+        tensors[path] = obj.detach().contiguous().cpu().clone()
+    elif isinstance(obj, dict):
+        if not all(isinstance(k, str) and "/" not in k for k in obj):
+            raise TypeError("packed tree keys must be strings without '/' (at %r)" % path)
+        tree[path] = {"t": "dict", "keys": list(obj)}
+        for k, v in obj.items():
+            _flatten(v, path + "/" + k, tensors, tree)
+    elif isinstance(obj, (tuple, list)):
+        tree[path] = {"t": "tuple" if isinstance(obj, tuple) else "list", "n": len(obj)}
+        for i, v in enumerate(obj):
+            _flatten(v, "%s/#%d" % (path, i), tensors, tree)
+    elif obj is None or isinstance(obj, (bool, int, float, str)):
+        tree[path] = {"t": "py", "v": obj}
+    else:
+        raise TypeError("cannot serialise %s in a packed tree (at %r)" % (type(obj).__name__, path))
+
+
+def _unflatten(path, get_tensor, tree):
+    node = tree[path]
+    if node["t"] == "tensor":
+        return get_tensor(path)
+    if node["t"] == "dict":
+        return {k: _unflatten(path + "/" + k, get_tensor, tree) for k in node["keys"]}
+    if node["t"] in ("tuple", "list"):
+        items = [_unflatten("%s/#%d" % (path, i), get_tensor, tree) for i in range(node["n"])]
+        return tuple(items) if node["t"] == "tuple" else items
+    return node["v"]
+
+
+def save_packed(path, **roots):
+    """save_packed("marconet.packed.safetensors", encoder=enc, gan=gan, sr=sr): packs (if not yet packed) every PackCache
+    holder of the given modules in its current precision and writes one file."""
+    import json
+    from safetensors.torch import save_file
+    tensors, trees, digests = {}, {}, {}
+    for rname, root in roots.items():
+        for hname, m in _holders(root):
+            prec = _holder_precision(m)
+            pk = m._cache.get(m, prec, m._build)
+            key = "%s|%s" % (rname + ("." + hname if hname else ""), prec)
+            flat, tree = {}, {}
+            _flatten(pk, "", flat, tree)
+            trees[key] = tree
+            digests[key] = _weights_digest(m)
+            for p, t in flat.items():
+                tensors[key + "|" + p] = t
+    if not tensors:
+        raise ValueError("save_packed: no packed-weight holders in the given modules")
+    save_file(tensors, path, metadata={"format": PACK_FORMAT, "trees": json.dumps(trees), "weights_sha256": json.dumps(digests)})
+    return sorted(trees)
+
+
+def load_packed(path, verify=True, **roots):
+    """attach a blob written by save_packed to modules that carry the SAME weights (checked by SHA-256 unless verify=False);
+    the next forward then uses the blob instead of re-packing.  Returns the list of holders that were attached."""
+    import json
+    from safetensors import safe_open
+    attached = []
+    with safe_open(path, framework="pt", device="cpu") as f:
+        meta = f.metadata() or {}
+        if meta.get("format") != PACK_FORMAT:
+            raise ValueError("%s is not a %s file" % (path, PACK_FORMAT))
+        trees, digests = json.loads(meta["trees"]), json.loads(meta["weights_sha256"])
+        for rname, root in roots.items():
+            for hname, m in _holders(root):
+                prec = _holder_precision(m)
+                key = "%s|%s" % (rname + ("." + hname if hname else ""), prec)
+                if key not in trees:
+                    raise KeyError("%s holds no packed weights for %s (has: %s)" % (path, key, ", ".join(sorted(trees))))
+                if verify and _weights_digest(m) != digests[key]:
+                    raise ValueError("packed blob %s was made from different weights than %s.%s carries" % (path, rname, hname))
+                dev = next(m.parameters()).device
+                pk = _unflatten("", lambda p: f.get_tensor(key + "|" + p).to(dev), trees[key])
+                sig = PackCache.signature(m)
+                if m._cache._sig != sig:
+                    m._cache._store, m._cache._sig = {}, sig
+                m._cache._store[prec] = pk
+                attached.append(key)
+    return attached

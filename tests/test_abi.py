@@ -228,3 +228,49 @@ def test_header_is_plain_c():
         with open(src, "w") as f:
             f.write('#include "marconet_hip.h"\nint main(void) { mnet_conv_desc d; (void)d; return mnet_abi_version != 0 ? 0 : 1; }\n')
         subprocess.check_call(["gcc", "-std=c99", "-pedantic", "-Werror", "-fsyntax-only", "-I", os.path.join(ROOT, "include"), src])
+
+
+def test_packed_blob_round_trip(ckpts, tmp_path):
+    """SURVEY §8(f) NEXT-3: save_packed → load_packed on fresh modules with the same weights reproduces the packed tree exactly and
+    the modules then never call their packer; a blob is refused for different weights"""
+    import pytest
+    import torch
+    from marconet_amd import networks
+    from marconet_amd.packing import load_packed, save_packed
+
+    def same(a, b):
+        if torch.is_tensor(a):
+            return torch.is_tensor(b) and a.dtype == b.dtype and a.shape == b.shape and torch.equal(a, b)
+        if isinstance(a, dict):
+            return isinstance(b, dict) and list(a) == list(b) and all(same(a[k], b[k]) for k in a)
+        if isinstance(a, (tuple, list)):
+            return type(a) is type(b) and len(a) == len(b) and all(same(x, y) for x, y in zip(a, b))
+        return a == b and type(a) is type(b)
+
+    enc, sr = networks.TextContextEncoderV2().eval(), networks.TSPSRNet().eval()
+    enc.load_state_dict(ckpts[0], strict=True)
+    sr.load_state_dict(ckpts[2], strict=True)
+    enc.set_precision("fp16")
+    sr.set_precision("fp16")
+    path = str(tmp_path / "marconet.packed.safetensors")
+    keys = save_packed(path, encoder=enc, sr=sr)
+    assert keys == ["encoder.resnet|fp16", "encoder.transformer|fp32", "sr|fp16"]
+    enc2, sr2 = networks.TextContextEncoderV2().eval(), networks.TSPSRNet().eval()
+    enc2.load_state_dict(ckpts[0], strict=True)
+    sr2.load_state_dict(ckpts[2], strict=True)
+    enc2.set_precision("fp16")
+    sr2.set_precision("fp16")
+    assert sorted(load_packed(path, encoder=enc2, sr=sr2)) == keys
+
+    def boom(_dtype):
+        raise AssertionError("packer called although a blob is attached")
+    for a, b, prec in ((enc.resnet, enc2.resnet, "fp16"), (enc.transformer, enc2.transformer, "fp32"), (sr, sr2, "fp16")):
+        got = b._cache.get(b, prec, boom)
+        assert same(a._cache.get(a, prec, boom), got)
+    with torch.no_grad():
+        sr2.conv_final[6].bias.add_(1.0)             # different weights → the blob must be refused (and, if forced, re-packed on use)
+    with pytest.raises(ValueError):
+        load_packed(path, sr=sr2)
+    sr2.set_precision("fp32")
+    with pytest.raises(KeyError):
+        load_packed(path, verify=False, sr=sr2)      # no fp32 pack of the SR net in this blob

@@ -383,3 +383,30 @@ def test_hip_graph_replay_equals_eager(nets, output):
             gf(lq, [labels[0], labels[2], labels[2]], locs)
     finally:
         pipe.set_precision("fp32")
+
+
+def test_packed_blob_drives_the_same_forward(nets, ckpts, tmp_path):
+    """SURVEY §8(f) NEXT-3: modules that attach an offline packed-weights blob (packing.save_packed / load_packed) instead of
+    packing at first use give the same bits"""
+    from marconet_amd import networks
+    from marconet_amd.packing import load_packed, save_packed
+    from marconet_amd.pipeline import MarconetPipeline
+    lq = synth.make_lq(51, 2, [512, 300]).to(DEV)
+    labels = [synth.make_labels(52, 4), synth.make_labels(53, 2)]
+    locs = synth.make_locs([4, 2], [512, 300])
+    pipe = MarconetPipeline(*nets, precision="fp16")
+    try:
+        want = pipe.forward_batch(lq, labels, locs)
+        path = str(tmp_path / "marconet.packed.safetensors")
+        keys = save_packed(path, encoder=nets[0], gan=nets[1], sr=nets[2])
+        fresh = [networks.TextContextEncoderV2(), networks.TSPGAN(), networks.TSPSRNet()]
+        for m, sd in zip(fresh, ckpts):
+            m.load_state_dict(sd, strict=True)
+            m.eval().to(DEV).set_precision("fp16")
+        assert sorted(load_packed(path, encoder=fresh[0], gan=fresh[1], sr=fresh[2])) == keys
+        for _, h in [x for m in fresh for x in __import__("marconet_amd.packing", fromlist=["_holders"])._holders(m)]:
+            h._build = None                                   # any attempt to re-pack would now raise
+        got = MarconetPipeline(*fresh, precision="fp16").forward_batch(lq, labels, locs)
+        assert torch.equal(got, want)
+    finally:
+        pipe.set_precision("fp32")
