@@ -359,7 +359,8 @@ static int adain_launch(const void* prior, const void* feat, void* out, int32_t 
     const size_t lds = (size_t)256 * N * 4 * sizeof(double) + (size_t)4 * C * sizeof(float) + (size_t)4 * C * sizeof(double) +
                        (size_t)(2 * C / 32) * 2 * sizeof(float);
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-    static thread_local size_t lds_set[2] = {0, 0};                    // attribute raised once per size (not during graph capture replays)
+    static thread_local size_t lds_all[256][2] = {};                   // attribute raised once per (device, size) (not during graph capture replays)
+    size_t* lds_set = lds_all[DeviceOnce::dev()];
     if (dtype == MNET_F16) {
         if (lds > lds_set[1]) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(adain_crop_kernel<f16>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); lds_set[1] = lds; }
         hipLaunchKernelGGL(adain_crop_kernel<f16>, dim3(G), dim3(256), lds, st, (const f16*)prior, (const f16*)feat, (f16*)out, S, C, feat_w,
@@ -549,10 +550,10 @@ extern "C" int mnet_adain_crop_concat_split(const void* prior, const void* feat,
     const size_t lds3 = (size_t)4 * C * sizeof(float);
     MNET_CHECK_ARG(lds2 <= 65536 && lds3 <= 65536, "adain_split: C=%d too large", C);
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-    static thread_local bool attr_set = false;
-    if (!attr_set) {
+    static thread_local DeviceOnce attr_once;
+    if (!attr_once.done()) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(adain_stats_kernel<f16>), hipFuncAttributeMaxDynamicSharedMemorySize, 256 * 8 * 4 * 8);
-        attr_set = true;
+        attr_once.mark();
     }
     if (dtype == MNET_F16) hipLaunchKernelGGL(adain_stats_kernel<f16>, dim3(slices, G), dim3(256), lds1, st, (const f16*)prior, (const f16*)feat, S, C, feat_w, g_img, g_x1, g_y1, g_w, partial, slices);
     else hipLaunchKernelGGL(adain_stats_kernel<float>, dim3(slices, G), dim3(256), lds1, st, (const float*)prior, (const float*)feat, S, C, feat_w, g_img, g_x1, g_y1, g_w, partial, slices);
@@ -967,11 +968,11 @@ extern "C" int mnet_conv3x3_rgb(const void* x, int32_t dtype, int32_t n, int32_t
         hipLaunchKernelGGL((conv3x3_rgb_kernel<f16, 64>), dim3(tiles, n), dim3(256), lds, st, (const f16*)x, wgt, bias, (f16*)y_nhwc, y_nchw, h, w, act);
     } else {
         const int lds = 10 * 34 * 64 * 4;
-        static thread_local bool attr_set = false;
-        if (!attr_set) {
+        static thread_local DeviceOnce attr_once;
+        if (!attr_once.done()) {
             hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_rgb_kernel<float, 64>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
             if (e != hipSuccess) return mnet_fail(MNET_E_LAUNCH, "hipFuncSetAttribute(conv3x3_rgb): %s", hipGetErrorString(e));
-            attr_set = true;
+            attr_once.mark();
         }
         hipLaunchKernelGGL((conv3x3_rgb_kernel<float, 64>), dim3(tiles, n), dim3(256), lds, st, (const float*)x, wgt, bias, (float*)y_nhwc, y_nchw, h, w, act);
     }

@@ -19,6 +19,16 @@ int mnet_fail(int code, const char* fmt, ...);
 #define MNET_LAUNCH_CHECK(what) do { hipError_t e__ = hipGetLastError(); \
     if (e__ != hipSuccess) return mnet_fail(MNET_E_LAUNCH, "%s: %s", what, hipGetErrorString(e__)); } while (0)
 
+// One-time per-device work of a kernel instantiation (hipFuncSetAttribute is per device): `static thread_local DeviceOnce once;`
+// then `if (!once.done()) { ...; once.mark(); }` — keyed by the CURRENT device, so a process that drives several GPUs raises the
+// attribute on each of them.
+struct DeviceOnce {
+    unsigned long long mask[4] = {0, 0, 0, 0};
+    static int dev() { int d = 0; if (hipGetDevice(&d) != hipSuccess || d < 0) d = 0; return d & 255; }
+    bool done() const { const int d = dev(); return (mask[d >> 6] >> (d & 63)) & 1ull; }
+    void mark() { const int d = dev(); mask[d >> 6] |= 1ull << (d & 63); }
+};
+
 static inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
 template <typename To, typename From>

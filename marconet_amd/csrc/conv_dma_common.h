@@ -131,12 +131,16 @@ __device__ __forceinline__ void dma_epilogue(const ConvArgs& p, const f32x4 (&ac
 
 // persistent grid: one workgroup per CU (every configuration needs > 80 KiB of LDS)
 static inline int dma_grid_limit() {
-    static const int ncu = [] {
-        int dev = 0, n = 0;
-        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+    static thread_local int ncu_of[256] = {};            // per device: a process may drive several GPUs
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0) dev = 0;
+    int& ncu = ncu_of[dev & 255];
+    if (ncu == 0) {
+        int n = 0;
+        if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
         const char* e = getenv("MNET_DMA_GRID");        // experiment knob: persistent workgroups (= CUs used) of the LDS-DMA kernels
         if (e && atoi(e) > 0 && atoi(e) < n) n = atoi(e);
-        return n;
-    }();
+        ncu = n;
+    }
     return ncu;
 }

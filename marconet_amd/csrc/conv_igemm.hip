@@ -294,12 +294,12 @@ template <typename T, int BC, int BP, int WC, int WP>
 static int launch_cfg(const ConvArgs& a, hipStream_t st) {
     constexpr int LDS = 2 * (BC + BP) * 128;
     auto kern = conv_igemm_kernel<T, BC, BP, WC, WP>;
-    static thread_local bool attr_set = false;   // per instantiation, per thread: idempotent and cheap
-    if (!attr_set) {
+    static thread_local DeviceOnce attr_once;      // per instantiation, per thread, per device
+    if (!attr_once.done()) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
         if (e != hipSuccess) return mnet_fail(MNET_E_LAUNCH, "hipFuncSetAttribute: %s", hipGetErrorString(e));
-        attr_set = true;
+        attr_once.mark();
     }
     ConvArgs b = a;
     b.tilesC = (a.cout + BC - 1) / BC;

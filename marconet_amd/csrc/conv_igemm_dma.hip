@@ -303,11 +303,11 @@ template <int BC, int BP, int WC, int WP, int STAGES, int MF = 16, int DBG = 0>
 static int launch_dma_cfg(const ConvArgs& a, hipStream_t st) {
     constexpr int LDS = STAGES * (BC + BP) * 128;
     auto kern = conv_dma_kernel<BC, BP, WC, WP, STAGES, MF, DBG>;
-    static thread_local bool attr_set = false;
-    if (!attr_set) {
+    static thread_local DeviceOnce attr_once;      // per instantiation, per thread, per device
+    if (!attr_once.done()) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
         if (e != hipSuccess) return mnet_fail(MNET_E_LAUNCH, "hipFuncSetAttribute(dma): %s", hipGetErrorString(e));
-        attr_set = true;
+        attr_once.mark();
     }
     ConvArgs b = a;
     b.tilesC = (a.cout + BC - 1) / BC;

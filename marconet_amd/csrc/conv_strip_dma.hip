@@ -233,11 +233,11 @@ static int launch_strip_cfg(const ConvArgs& a, hipStream_t st) {
     constexpr int LDS = 2 * BC * 128 + 2 * StripCap<BP>::ROWS * 128;
     static_assert(LDS <= 160 * 1024, "LDS budget");
     auto kern = conv_strip_kernel<BC, BP, WC, WP>;
-    static thread_local bool attr_set = false;
-    if (!attr_set) {
+    static thread_local DeviceOnce attr_once;      // per instantiation, per thread, per device
+    if (!attr_once.done()) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
         if (e != hipSuccess) return mnet_fail(MNET_E_LAUNCH, "hipFuncSetAttribute(strip): %s", hipGetErrorString(e));
-        attr_set = true;
+        attr_once.mark();
     }
     ConvArgs b = a;
     b.tilesC = (a.cout + BC - 1) / BC;

@@ -17,7 +17,7 @@ from . import ops
 
 def fused_leaky_relu(input, bias, negative_slope=0.2, scale=2 ** 0.5):
     """out = scale * leaky_relu(input + bias.view(1, C, 1, ...), negative_slope); inference only (no autograd)."""
-    with torch.no_grad():
+    with torch.no_grad(), ops.on_device(input):
         x = input.contiguous().float()
         b = None if bias is None else bias.detach().contiguous().float()
         return ops.fused_bias_act(x, b, negative_slope, scale)

@@ -50,7 +50,7 @@ class TextContextEncoderV2(nn.Module, _Precision):
         self.resnet.precision = self.precision
 
     def forward(self, lq):
-        with torch.no_grad():
+        with torch.no_grad(), ops.on_device(lq):
             self.resnet.precision = self.precision
             x = ops.nchw_to_nhwc(lq.contiguous().float(), torch_dtype(self.precision), c_ld=8)
             feat = self.resnet.forward_nhwc(x)
@@ -244,7 +244,6 @@ class TextGenerator(nn.Module):
         x = self._styled(pk["conv1"], x, s, d, premodulated=False)
         skip = self._to_rgb(pk["rgb1"], x, lat, None) if need_image else None
         p64 = p32 = None
-        nc = labels.shape[1]
         for lvl in range(len(pk["rgbs"])):
             if not need_image and p64 is not None and p32 is not None:
                 return None, p64, p32
@@ -258,14 +257,18 @@ class TextGenerator(nn.Module):
             del xa
             if need_image:
                 skip = self._to_rgb(pk["rgbs"][lvl], x, lat, skip)
-            if x.shape[2] == 64 * nc:
-                p64 = x
-            if x.shape[2] == 32 * nc:
+            if x.shape[2] == 64:              # ABSOLUTE width, like the reference (:155,158): with c characters per
+                p64 = x                       # sample the map is 4c·2^k wide, so c = 2 hands out the 32x64 / 16x32 levels
+            if x.shape[2] == 32:
                 p32 = x
+        if p64 is None or p32 is None:
+            # the reference reaches `return image, prior_features64, prior_features32` with an unbound local here
+            raise RuntimeError("no generator level is 64 / 32 pixels wide for %d characters per sample "
+                               "(models/networks.py:155-160 selects the prior levels by absolute width)" % labels.shape[1])
         return skip, p64, p32
 
     def forward(self, styles, labels, noise=None):
-        with torch.no_grad():
+        with torch.no_grad(), ops.on_device(styles):
             styles = styles.contiguous().float()
             labels = labels.to(styles.device).contiguous().long()
             if labels.dim() != 2 or labels.shape[0] != styles.shape[0]:
@@ -276,7 +279,8 @@ class TextGenerator(nn.Module):
             img, p64, p32 = self.forward_nhwc(styles, labels)
             out = ops.nhwc_to_nchw(img, c=3), ops.nhwc_to_nchw(p64), ops.nhwc_to_nchw(p32)
             # keep the NHWC originals reachable so TSPSRNet can skip the NCHW→NHWC round trip
-            out[1]._mnet_nhwc, out[2]._mnet_nhwc = p64, p32
+            # (valid only while the NCHW tensor is unmodified: its version counter and address are recorded with the shadow)
+            out[1]._mnet_nhwc, out[2]._mnet_nhwc = (p64, out[1]._version, out[1].data_ptr()), (p32, out[2]._version, out[2].data_ptr())
             return out
 
 
@@ -441,9 +445,10 @@ class TSPSRNet(nn.Module, _Precision):
                 continue
             if p.dim() != 4 or p.shape[1] != channels or p.shape[2] != size or p.shape[3] != size:
                 raise ValueError("prior of shape %s, expected [n,%d,%d,%d]" % (tuple(p.shape), channels, size, size))
-            nh = getattr(p, "_mnet_nhwc", None)
-            if nh is not None and nh.dtype == dtype and nh.shape[0] == p.shape[0]:
-                parts.append(nh)
+            sh = getattr(p, "_mnet_nhwc", None)
+            # the NHWC original is used only if the caller has not touched the NCHW tensor since (in-place edits bump _version)
+            if sh is not None and sh[0].dtype == dtype and sh[0].shape[0] == p.shape[0] and sh[1] == p._version and sh[2] == p.data_ptr():
+                parts.append(sh[0])
             else:
                 parts.append(ops.nchw_to_nhwc(p.contiguous().float(), dtype))
         if not parts:
@@ -453,7 +458,7 @@ class TSPSRNet(nn.Module, _Precision):
     # ------------------------------------------------------------------ forward
     def forward(self, lq, priors64, priors32, locs):
         """reference call form (test_sr.py:197): lists (one entry per image) of NCHW fp32 priors."""
-        with torch.no_grad():
+        with torch.no_grad(), ops.on_device(lq):
             dtype = torch_dtype(self.precision)
             B = lq.shape[0]
             if len(priors32) > B or len(priors64) > B:
@@ -469,7 +474,7 @@ class TSPSRNet(nn.Module, _Precision):
         images back to back (``counts*[b]`` glyphs for image b).  Returns NHWC [B,128,2048,8] (RGB in channels 0-2), or —
         ``nchw_out`` — the reference's fp32 NCHW [B,3,128,2048] written by the last conv itself.  ``tables``: prebuilt
         (GlyphTables@32, GlyphTables@64) instead of ``locs`` (the HIP-graph path keeps them at fixed device addresses)."""
-        with torch.no_grad():
+        with torch.no_grad(), ops.on_device(lq):
             pk = self._cache.get(self, self.precision, self._build)
             dtype = torch_dtype(self.precision)
             x = ops.nchw_to_nhwc(lq.contiguous().float(), dtype, c_ld=8)

@@ -35,11 +35,29 @@ def _stream():
 
 
 def _need_cuda(*ts):
+    """every tensor of a launch must be contiguous and live on the CURRENT HIP device: the C side launches on the current
+    device, on that device's current stream (the module forwards enter ``torch.cuda.device(input.device)`` first)"""
+    cur = None
     for t in ts:
-        if t is not None and not t.is_cuda:
+        if t is None:
+            continue
+        if not t.is_cuda:
             raise RuntimeError("marconet_amd: tensors must live on a HIP device (got %s); there is no CPU path" % t.device)
-        if t is not None and not t.is_contiguous():
+        if cur is None:
+            cur = torch.cuda.current_device()
+        if t.device.index != cur:
+            raise RuntimeError("marconet_amd: tensor on %s but the current device is cuda:%d — enter torch.cuda.device(...) "
+                               "(the nn.Module forwards and MarconetPipeline do)" % (t.device, cur))
+        if not t.is_contiguous():
             raise RuntimeError("marconet_amd: non-contiguous tensor passed to a kernel wrapper")
+
+
+def on_device(t):
+    """context manager: the HIP device of ``t`` becomes the current device (launches and the stream lookup follow the current
+    device); a CPU tensor raises — there is no CPU path"""
+    if not t.is_cuda:
+        raise RuntimeError("marconet_amd: tensors must live on a HIP device (got %s); there is no CPU path" % t.device)
+    return torch.cuda.device(t.device)
 
 
 class _Stats:

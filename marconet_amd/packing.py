@@ -99,7 +99,14 @@ def equal_linear_scale(in_channels, lr_mul):
 # safetensors container: one entry per packed tensor, named "<root>[.<holder>]|<precision>|<path in the packed tree>", the tree
 # structure and the non-tensor leaves as JSON metadata, and a SHA-256 of each holder's parameters so that a blob is never
 # attached to different weights.
-PACK_FORMAT = "marconet_amd.packed.v1"
+PACK_FORMAT = "marconet_amd.packed.v2"
+PACK_LAYOUT = 2        # bump whenever any holder's _build() changes what it emits (keys, padding, layouts): a blob written by a
+                       # different _build must not attach (it would fail with a KeyError mid-forward, or be read with another layout)
+
+
+def _abi_version():
+    from . import _lib
+    return int(_lib.ABI_VERSION)
 
 
 def _holders(root):
@@ -115,7 +122,7 @@ def _weights_digest(m):
     import hashlib
     h = hashlib.sha256()
     for name, t in list(m.named_parameters()) + list(m.named_buffers()):
-        h.update(name.encode())
+        h.update(("%s|%s|%s|" % (name, tuple(t.shape), t.dtype)).encode())
         h.update(t.detach().contiguous().cpu().numpy().tobytes())
     return h.hexdigest()
 
@@ -171,7 +178,8 @@ def save_packed(path, **roots):
                 tensors[key + "|" + p] = t
     if not tensors:
         raise ValueError("save_packed: no packed-weight holders in the given modules")
-    save_file(tensors, path, metadata={"format": PACK_FORMAT, "trees": json.dumps(trees), "weights_sha256": json.dumps(digests)})
+    save_file(tensors, path, metadata={"format": PACK_FORMAT, "layout": str(PACK_LAYOUT), "abi": str(_abi_version()),
+                                       "trees": json.dumps(trees), "weights_sha256": json.dumps(digests)})
     return sorted(trees)
 
 
@@ -185,6 +193,9 @@ def load_packed(path, verify=True, **roots):
         meta = f.metadata() or {}
         if meta.get("format") != PACK_FORMAT:
             raise ValueError("%s is not a %s file" % (path, PACK_FORMAT))
+        if meta.get("layout") != str(PACK_LAYOUT) or meta.get("abi") != str(_abi_version()):
+            raise ValueError("%s was written by packing layout %s / C-ABI %s; this build is layout %d / C-ABI %d — re-run save_packed"
+                             % (path, meta.get("layout"), meta.get("abi"), PACK_LAYOUT, _abi_version()))
         trees, digests = json.loads(meta["trees"]), json.loads(meta["weights_sha256"])
         for rname, root in roots.items():
             for hname, m in _holders(root):

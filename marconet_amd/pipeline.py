@@ -11,7 +11,7 @@ collective and no weight traffic.
 import torch
 
 from . import ops
-from .packing import torch_dtype
+from .packing import default_precision, torch_dtype
 
 
 import os as _os
@@ -19,13 +19,24 @@ _NO_STYLE_DEDUPE = bool(int(_os.environ.get("MNET_NO_STYLE_DEDUPE", "0")))      
 
 
 class MarconetPipeline:
-    def __init__(self, encoder, gan, sr, precision="fp16", glyph_chunk=1024, need_prior_image=True):
+    def __init__(self, encoder, gan, sr, precision=None, glyph_chunk=1024, need_prior_image=True, check_finite=None):
+        """``precision``: None → MARCONET_PRECISION or "fp32" (the parity mode, ≤1e-3 vs the CPU reference).  The fp16
+        storage modes are opt-in: plain "fp16" stores activations as one half (max 65504, 11 significant bits) and has only
+        been validated on O(1)-activation synthetic checkpoints — with trained StyleGAN-type weights a modulated activation
+        can overflow.  ``check_finite`` (default: on for every precision but fp32) makes forward_batch verify that the SR
+        result is finite (one flag read back per batch) and raise FloatingPointError instead of returning inf/NaN silently."""
         self.encoder, self.gan, self.sr = encoder, gan, sr
         self.glyph_chunk = glyph_chunk
+        self.check_finite = check_finite
+        self._finite = None
+        precision = default_precision() if precision is None else precision
         # True (default): the generator also produces its 128-px structure image, as test_sr.py:183 does (it is only ever
         # used for the saved visualisation, test_sr.py:203-232).  False is an opt-in for throughput serving.
         self.need_prior_image = need_prior_image
         self.set_precision(precision)
+
+    def _checks(self):
+        return self.check_finite if self.check_finite is not None else self.precision != "fp32"
 
     def set_precision(self, precision):
         for m in (self.encoder, self.gan, self.sr):
@@ -42,8 +53,13 @@ class MarconetPipeline:
         to copy to the host or to all-gather)."""
         dev = lq.device
         counts = [int(l.shape[0]) for l in labels]
-        lab, img_of = self._host_prep(labels, counts, dev)
-        return self._core(lq, lab, img_of, counts, locs, None, return_nhwc, output)
+        with ops.on_device(lq):
+            lab, img_of = self._host_prep(labels, counts, dev)
+            y = self._core(lq, lab, img_of, counts, locs, None, return_nhwc, output)
+            if self._checks() and self._finite is not None and not bool(self._finite):
+                raise FloatingPointError("marconet_amd: non-finite SR output in %s mode (half-precision overflow?) — use "
+                                         "precision='fp32' or 'fp16x3' for these weights" % self.precision)
+            return y
 
     def _host_prep(self, labels, counts, dev):
         """labels (host or device) → validated device tensors (labels [ΣN,1], glyph→image index [ΣN])"""
@@ -84,8 +100,11 @@ class MarconetPipeline:
         else:
             p64 = p32 = None
         if output != "u8_bgr" and not return_nhwc:
-            return self.sr.forward_packed(lq, p64, p32, counts, counts, locs, nchw_out=True, tables=tables)   # test_sr.py:197
+            y = self.sr.forward_packed(lq, p64, p32, counts, counts, locs, nchw_out=True, tables=tables)   # test_sr.py:197
+            self._finite = torch.isfinite(y).all() if self._checks() else None   # device-side flag: no synchronisation here
+            return y
         y = self.sr.forward_packed(lq, p64, p32, counts, counts, locs, tables=tables)
+        self._finite = torch.isfinite(y).all() if self._checks() else None
         if output == "u8_bgr":                                           # test_sr.py:198-200 fused: [B,128,2048,3] uint8
             return ops.sr_postprocess(y, u8=True)
         return y if return_nhwc else ops.nhwc_to_nchw(y, c=3)
@@ -131,7 +150,7 @@ class MarconetPipeline:
             cb = [counts[b] for b in idx]
             it = torch.tensor(idx, device=dev)
             lq_b = lq.index_select(0, it)[:, :, :, :wb].contiguous()
-            locs_b = (locs.index_select(0, it).float() * (512.0 / wb)).contiguous()
+            locs_b = (locs.to(dev).index_select(0, it).float() * (512.0 / wb)).contiguous()
             if gsel:
                 gt = torch.tensor(gsel, device=dev)
                 a, c = p64.index_select(0, gt), p32.index_select(0, gt)
@@ -142,6 +161,30 @@ class MarconetPipeline:
                 out[b] = y[k]
         return out
 
+
+    @torch.no_grad()
+    def restore_strips(self, strips):
+        """The body of test_sr.py's ``for img_name`` loop (:77-201) for a list of strips prepared by ``lq_io.strip_from_png``
+        (dicts with lq [1,3,32,512], labels int64 [n,1], locs [1,2n], show_w) — as ONE batch.  → list of uint8 BGR arrays
+        [128, show_w, 3] on the host (``ShowSR``, test_sr.py:198-201: the post-processed SR result cropped to the content
+        width); ``None`` for a strip the script would skip (a character outside the alphabet → label −1 → the generator
+        raises, test_sr.py:181-190; no character at all, :168-170)."""
+        dev = next(self.sr.parameters()).device
+        n_cls = self.gan.TextGenerator.class_num
+        keep = [i for i, s in enumerate(strips)
+                if s["labels"].numel() > 0 and int(s["labels"].min()) >= 0 and int(s["labels"].max()) < n_cls]
+        out = [None] * len(strips)
+        if not keep:
+            return out
+        m = max(int(strips[i]["labels"].shape[0]) for i in keep)
+        locs = torch.zeros((len(keep), 2 * m), dtype=torch.float32)
+        for k, i in enumerate(keep):
+            locs[k, :strips[i]["locs"].shape[1]] = strips[i]["locs"][0]
+        lq = torch.cat([strips[i]["lq"] for i in keep]).to(dev)
+        y = self.forward_batch(lq, [strips[i]["labels"] for i in keep], locs, output="u8_bgr").cpu().numpy()
+        for k, i in enumerate(keep):
+            out[i] = y[k, :, :strips[i]["show_w"], :]
+        return out
 
     @torch.no_grad()
     def forward_blind(self, lq, max_glyphs=16):

@@ -83,7 +83,7 @@ class ResNet(nn.Module):
 
     def forward(self, x):
         """NCHW fp32 in → NCHW fp32 out, like the reference (models/resnet.py:63-71)."""
-        with torch.no_grad():
+        with torch.no_grad(), ops.on_device(x):
             h = ops.nchw_to_nhwc(x.contiguous().float(), torch_dtype(self.precision), c_ld=8)
             return ops.nhwc_to_nchw(self.forward_nhwc(h))
 

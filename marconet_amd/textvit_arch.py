@@ -130,6 +130,6 @@ class TextViT(nn.Module):
 
     def forward(self, img):
         """img: NCHW fp32 [B,512,8,512] like the reference (textvit_arch.py:65-77)."""
-        with torch.no_grad():
+        with torch.no_grad(), ops.on_device(img):
             feat = ops.nchw_to_nhwc(img.contiguous().float(), torch.float32)
             return self.forward_nhwc(feat)

@@ -205,9 +205,9 @@ def tspgan_forward(sd, styles, labels, prefix="TextGenerator."):
         x = _styled_conv(sd, "%sconvs.%d" % (prefix, 2 * lvl), x, lat, True)
         x = _styled_conv(sd, "%sconvs.%d" % (prefix, 2 * lvl + 1), x, lat, False)
         skip = _to_rgb(sd, "%sto_rgbs.%d" % (prefix, lvl), x, lat, skip)
-        if x.shape[-1] == 64 * c:
+        if x.shape[-1] == 64:                 # absolute width (networks.py:155,158)
             p64 = x
-        if x.shape[-1] == 32 * c:
+        if x.shape[-1] == 32:
             p32 = x
     return skip, p64, p32
 

@@ -20,9 +20,8 @@ def reference_available() -> bool:
     return os.path.isfile(os.path.join(REFERENCE_ROOT, "models", "networks.py"))
 
 
-def _install_fused_act_stub():
-    if "basicsr.ops.fused_act" in sys.modules:
-        return
+def _fused_act_stub_modules():
+    """pure-torch ``basicsr`` / ``basicsr.ops`` / ``basicsr.ops.fused_act`` module objects with upstream semantics"""
     import torch
     import torch.nn as nn
     import torch.nn.functional as F
@@ -48,17 +47,44 @@ def _install_fused_act_stub():
     fa.FusedLeakyReLU = FusedLeakyReLU
     pkg.ops = ops
     ops.fused_act = fa
-    sys.modules["basicsr"] = pkg
-    sys.modules["basicsr.ops"] = ops
-    sys.modules["basicsr.ops.fused_act"] = fa
+    return {"basicsr": pkg, "basicsr.ops": ops, "basicsr.ops.fused_act": fa}
+
+
+_REF_NETWORKS = None
 
 
 def load_reference_networks():
-    """Returns the reference's ``models.networks`` module (unmodified source, imported in place)."""
+    """Returns the reference's ``models.networks`` module (unmodified source, imported in place).
+
+    The repo root carries its own drop-in ``models`` package (the HIP classes) and may have registered the HIP
+    ``basicsr.ops.fused_act`` provider; the reference is therefore imported with ``sys.modules['models*']`` and
+    ``sys.modules['basicsr*']`` swapped out for the duration of the import and restored afterwards — the reference module
+    keeps the names it bound at import time, the rest of the process keeps seeing the drop-in package."""
+    global _REF_NETWORKS
+    if _REF_NETWORKS is not None:
+        return _REF_NETWORKS
     if not reference_available():
         raise RuntimeError("reference tree not present at %s" % REFERENCE_ROOT)
-    _install_fused_act_stub()
-    if REFERENCE_ROOT not in sys.path:
-        sys.path.insert(0, REFERENCE_ROOT)
     import importlib
-    return importlib.import_module("models.networks")
+    swapped = {k: sys.modules.pop(k) for k in list(sys.modules)
+               if k == "models" or k.startswith("models.") or k == "basicsr" or k.startswith("basicsr.")}
+    sys.modules.update(_fused_act_stub_modules())
+    sys.path.insert(0, REFERENCE_ROOT)
+    try:
+        importlib.invalidate_caches()
+        # the reference's models/ has no __init__.py (a namespace package): a regular package of the same name anywhere on
+        # sys.path — the drop-in at the repo root — would win the lookup, so the package object is pinned to the reference
+        # directory explicitly
+        ref_pkg = types.ModuleType("models")
+        ref_pkg.__path__ = [os.path.join(REFERENCE_ROOT, "models")]
+        sys.modules["models"] = ref_pkg
+        mod = importlib.import_module("models.networks")
+        if not os.path.abspath(mod.__file__).startswith(os.path.abspath(REFERENCE_ROOT)):
+            raise RuntimeError("models.networks resolved to %s, not the reference tree" % mod.__file__)
+    finally:
+        sys.path.remove(REFERENCE_ROOT)
+        for k in [k for k in sys.modules if k == "models" or k.startswith("models.") or k == "basicsr" or k.startswith("basicsr.")]:
+            del sys.modules[k]
+        sys.modules.update(swapped)
+    _REF_NETWORKS = mod
+    return mod

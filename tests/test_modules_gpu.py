@@ -111,6 +111,7 @@ def test_gan_two_chars_per_sample(nets, ckpts):
         ref = O.tspgan_forward(ckpts[1], styles, labels)
     out = nets[1](styles=styles.to(DEV), labels=labels.to(DEV), noise=None)
     assert out[0].shape == (2, 3, 128, 256)
+    assert out[1].shape == (2, 512, 32, 64) and out[2].shape == (2, 512, 16, 32)     # levels picked by absolute width (:155,158)
     for a, b in zip(out, ref):
         assert _err(a, b) <= TOL
 

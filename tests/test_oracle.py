@@ -107,5 +107,12 @@ def test_oracle_equals_real_reference(ckpts):
         assert (y_ref - y_or).abs().max().item() <= 1e-6
     # the fused_act shim restates upstream semantics (unpinned third-party boundary)
     x, bias = torch.randn(2, 5, 3, 3), torch.randn(5)
-    from basicsr.ops.fused_act import fused_leaky_relu
-    assert torch.equal(fused_leaky_relu(x, bias), O.fused_leaky_relu(x, bias))
+    assert torch.equal(nw.fused_leaky_relu(x, bias), O.fused_leaky_relu(x, bias))     # the name the reference bound at import
+    # two characters per sample: the reference picks the prior levels by ABSOLUTE width (models/networks.py:155,158)
+    st2, lab2 = synth.make_styles(31, 2), synth.make_labels(32, 4).reshape(2, 2)
+    with torch.no_grad():
+        r2 = gan(styles=st2, labels=lab2, noise=None)
+        o2 = O.tspgan_forward(ckpts[1], st2, lab2)
+    assert r2[1].shape == (2, 512, 32, 64) and r2[2].shape == (2, 512, 16, 32)
+    for x, y in zip(r2, o2):
+        assert x.shape == y.shape and (x - y).abs().max().item() <= 1e-6

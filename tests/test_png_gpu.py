@@ -1,0 +1,92 @@
+"""-m gpu: BASELINE configs[0] on the HIP path — the reference's own test strips (tests/golden/pngs/) through the script
+plumbing (marconet_amd/lq_io.py), the three HIP networks in the reference's call forms, and the K19 post-processing; against
+tests/golden/golden_png_v1.npz (the REAL reference modules run on the same strips, tests/golden/make_golden_png.py) and
+against the CPU oracle.  Also the test_w.py path on Testsets/TestW (clear_labels + style interpolation)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from marconet_amd import lq_io
+from oracle import marconet_oracle as O
+from oracle import script_plumbing as SP
+from tests.golden import cases_png
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def golden_png():
+    return dict(np.load(os.path.join(ROOT, "tests", "golden", "golden_png_v1.npz")))
+
+
+@pytest.fixture(scope="module")
+def nets(ckpts):
+    from models import networks                    # the drop-in package: test_sr.py:6
+    enc, gan, sr = networks.TextContextEncoderV2(), networks.TSPGAN(), networks.TSPSRNet()
+    enc.load_state_dict(ckpts[0], strict=True)
+    gan.load_state_dict(ckpts[1], strict=True)
+    sr.load_state_dict(ckpts[2], strict=True)
+    return [m.eval().to(DEV).set_precision("fp32") for m in (enc, gan, sr)]
+
+
+@pytest.mark.parametrize("tag", list(cases_png.SR_STRIPS))
+def test_png_through_script_call_forms(tag, nets, golden_png):
+    """test_sr.py:146-201 with the HIP modules, one strip per call exactly as the script does it"""
+    enc, gan, sr = nets
+    s = lq_io.strip_from_png(os.path.join(cases_png.PNG_DIR, cases_png.SR_STRIPS[tag]))
+    LQ = s["lq"].to(DEV)
+    with torch.no_grad():
+        logits, _, w = enc(LQ)
+        w0 = w[:1, ...].clone()
+        labels = s["labels"]
+        prior_cha, f64, f32 = gan(styles=w0.repeat(labels.size(0), 1), labels=labels, noise=None)
+        y = sr(LQ, [f64], [f32], s["locs"].to(DEV))
+    assert np.array_equal(logits.argmax(-1).cpu().numpy(), golden_png["sr.%s.argmax" % tag])
+    err = float(np.abs(y[:, :, ::4, ::8].cpu().numpy() - golden_png["sr.%s.raw_s" % tag]).max())
+    print("png %s: HIP fp32 vs real reference %.3e" % (tag, err))
+    assert err <= 1e-3
+    bgr = SP.postprocess(y)                        # the script's own post-processing on the HIP result
+    d = np.abs(cases_png.sample_bgr(SP.to_u8(bgr)).astype(int) - golden_png["sr.%s.bgr_u8_s" % tag].astype(int))
+    assert d.max() <= 1 and (d > 0).mean() < 0.02
+
+
+def test_png_batch_through_pipeline_vs_oracle(nets, ckpts):
+    """both strips (+ one the script would skip) as one batch through MarconetPipeline.restore_strips → cropped uint8 BGR"""
+    from marconet_amd.pipeline import MarconetPipeline
+    pipe = MarconetPipeline(*nets, precision="fp32")
+    strips = [lq_io.strip_from_png(os.path.join(cases_png.PNG_DIR, f)) for f in cases_png.SR_STRIPS.values()]
+    bad = lq_io.strip_from_png(os.path.join(cases_png.PNG_DIR, "real_lq13.png"), text="ab")      # a character outside the alphabet
+    assert int(bad["labels"].min()) == -1
+    outs = pipe.restore_strips([strips[0], bad, strips[1]])
+    assert outs[1] is None
+    for s, o in zip(strips, (outs[0], outs[2])):
+        r = O.end_to_end(ckpts[0], ckpts[1], ckpts[2], s["lq"], [s["labels"]], s["locs"])
+        ref = SP.to_u8(SP.postprocess(r["sr"]))[:, :s["show_w"], :]
+        assert o.shape == ref.shape == (128, s["show_w"], 3) and o.dtype == np.uint8
+        d = np.abs(o.astype(int) - ref.astype(int))
+        assert d.max() <= 1 and (d > 0).mean() < 0.02
+
+
+def test_w_strips_clear_labels_and_interpolation(nets, golden_png):
+    """test_w.py:59-108 on Testsets/TestW/w1.png / w2.png"""
+    from marconet_amd.pipeline import clear_labels_batch, w_interpolation
+    enc, gan, _ = nets
+    l1, _, _ = lq_io.lq_from_image(lq_io.load_png(os.path.join(cases_png.PNG_DIR, cases_png.W_STRIPS[0])))
+    l2, _, _ = lq_io.lq_from_image(lq_io.load_png(os.path.join(cases_png.PNG_DIR, cases_png.W_STRIPS[1])))
+    with torch.no_grad():
+        p1, _, w1 = enc(l1.to(DEV))
+        _, _, w2 = enc(l2.to(DEV))
+    lab = clear_labels_batch(p1)[0]
+    assert lab.flatten().tolist() == golden_png["w.labels"].tolist()
+    assert float(np.abs(w1.cpu().numpy() - golden_png["w.w1"]).max()) <= 1e-3
+    assert float(np.abs(w2.cpu().numpy() - golden_png["w.w2"]).max()) <= 1e-3
+    labt = lab[:cases_png.W_MAX_GLYPHS]
+    imgs = w_interpolation(gan, w1, w2, labt, steps=3)                # s = 0, 0.5, 1
+    for k, scale in enumerate(cases_png.W_SCALES):
+        err = float(np.abs(imgs[k][:, :, ::4, ::4].cpu().numpy() - golden_png["w.img_%.2f_s" % scale]).max())
+        print("w interpolation %.2f: %.3e" % (scale, err))
+        assert err <= 1e-3
