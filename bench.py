@@ -5,13 +5,20 @@
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
 
-One "step" = one pass of the whole hot path (ResNet-45 + TextViT encoder → TSPGAN over all glyphs → TSPSRNet)
-over one batch of synthetic 32x512 LR strips per GPU (BASELINE.json configs[1]: batch 64, fp16 storage with fp32
-accumulation/statistics, 16 glyphs per image), inputs resident in HBM, random-init seeded checkpoints of the
-reference's exact architecture.  N>1: weak scaling, every rank processes its own batch and the SR outputs are
-all-gathered over RCCL (the one collective of the path).  Rank 0 prints ONE JSON line.
+One "step" = one pass of the whole hot path (ResNet-45 + TextViT encoder → TSPGAN over all glyphs → TSPSRNet) over one
+batch of synthetic 32x512 LR strips per GPU — by default the configuration BASELINE.json's metric is quoted on: batch 256
+per GPU, 16 glyphs per image, inputs resident in HBM, random-init seeded checkpoints of the reference's exact architecture.
+(`--batch 64` is BASELINE configs[1]; `--gpus 8 --batch 128` is configs[2].)  N>1: weak scaling, every rank processes its
+own batch and the post-processed SR outputs (uint8 BGR, test_sr.py:198-200) are all-gathered over RCCL — the one collective
+of the path.  Rank 0 prints ONE JSON line.
+
+Other BASELINE configs, each with its own roofline of its dominant kernel:
+    --config gan     configs[3]: the test_w.py StyleGAN-prior path alone — 256 x 16 = 4096 glyphs of 128x128 through TSPGAN
+    --config mixed   configs[4]: strips of content width 128..512 bucketed by padded width (MarconetPipeline.forward_mixed_widths),
+                     work-balanced over the ranks for N>1
 """
 import argparse
+import hashlib
 import json
 import os
 import sys
@@ -23,9 +30,31 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 PEAK_F16_TFLOPS = 2500.0       # MI355X dense fp16 MFMA (MI355X_MICROARCH.md)
-GF_F16_FIXED = 108.01 + 484.12  # ResNet + SR trunk, GFLOP / image
-GF_F16_PER_GLYPH = 41.78 + 47.25
-GF_FP32_VIT = 3.69
+PEAK_F32_TFLOPS = 157.3        # fp32 matrix (v_mfma_f32_16x16x4_f32)
+PEAK_F16X3_TFLOPS = PEAK_F16_TFLOPS / 3.0    # split-precision: three fp16 MFMA products per algorithmic product
+GF_RESNET, GF_VIT, GF_SR_TRUNK = 108.01, 3.69, 484.12     # GFLOP / image
+GF_GAN, GF_SR_PRIOR = 41.78, 47.25                         # GFLOP / glyph
+GF_F16_FIXED = GF_RESNET + GF_SR_TRUNK
+GF_F16_PER_GLYPH = GF_GAN + GF_SR_PRIOR
+
+# kernel id (mnet_conv2d_plan) → name as it appears in rocprofv3's kernel trace
+KNAME = {1: "conv_igemm_kernel (register-staged)", 3: "conv_skinny_f32_kernel", 16: "conv_dma_kernel<256,256,4,4,2,16>", 17: "conv_dma_kernel<256,128,4,2,3,16>",
+         18: "conv_dma_kernel<128,256,2,4,3,16>", 19: "conv_dma_kernel<64,256,1,8,3,16>", 20: "conv_dma_kernel<128,512,2,8,2,16>",
+         21: "conv_dma_kernel<64,512,1,8,2,16>", 22: "conv_dma_kernel<256,256,2,4,2,16>", 26: "conv_dma_kernel<128,128,2,4,4,16>",
+         32: "conv_strip_kernel<256,256,4,4>", 33: "conv_strip_kernel<64,512,1,8>", 34: "conv_strip_kernel<128,256,2,4>"}
+DTNAME = {0: "f32", 1: "f16", 2: "f16x3"}
+DTPEAK = {0: PEAK_F32_TFLOPS, 1: PEAK_F16_TFLOPS, 2: PEAK_F16X3_TFLOPS}
+# sources whose content decides the dominant kernel's HBM traffic: the PMC figure in profiles/pmc_traffic.json is reported
+# only while these files are the ones it was measured on (else it is stale and `traffic` is null)
+KERNEL_SOURCES = ["marconet_amd/csrc/conv_igemm_dma.hip", "marconet_amd/csrc/conv_dma_common.h", "marconet_amd/csrc/conv_args.h"]
+
+
+def kernel_sources_sha():
+    h = hashlib.sha256()
+    for f in KERNEL_SOURCES:
+        with open(os.path.join(ROOT, f), "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
 
 
 def parse():
@@ -33,14 +62,91 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--batch", type=int, default=64, help="images per GPU (configs[1]: 64)")
+    ap.add_argument("--config", default="sr", choices=["sr", "gan", "mixed"], help="sr: the headline path; gan: configs[3]; mixed: configs[4]")
+    ap.add_argument("--batch", type=int, default=256, help="images per GPU (the metric's batch 256; configs[1]: 64; configs[2]: 128 on 8 GPUs)")
     ap.add_argument("--glyphs", type=int, default=16, help="glyphs per image (SURVEY.md §8d: n=16)")
-    ap.add_argument("--precision", default="fp16", choices=["fp16", "fp32"])
+    ap.add_argument("--precision", default="fp16", choices=["fp16", "fp32", "fp16x3"])
     ap.add_argument("--cpu-images", type=int, default=4, help="images timed on the host CPU oracle (0 = skip); ~3.5 s each on 32 threads")
-    ap.add_argument("--no-secondary", action="store_true", help="skip the secondary (no structure-image) throughput measurement")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the secondary throughput measurements")
     ap.add_argument("--cpu-threads", type=int, default=32, help="cap on host threads for the CPU baseline")
     ap.add_argument("--no-gather", action="store_true")
+    ap.add_argument("--gather-format", default="u8", choices=["u8", "f32"], help="N>1: what is all-gathered — the post-processed uint8 BGR image (0.75 MiB/img) or the fp32 NCHW tensor (3 MiB/img)")
     return ap.parse_args()
+
+
+def host_threads(cap):
+    try:
+        avail = len(os.sched_getaffinity(0))
+    except AttributeError:
+        avail = os.cpu_count() or 1
+    return max(1, min(avail, cap))
+
+
+def timed(step, fence, steps, world, dev):
+    import torch.distributed as dist
+    fence()
+    t0 = time.perf_counter()
+    y = None
+    for _ in range(steps):
+        y = step()
+    fence()
+    dt = time.perf_counter() - t0
+    per_rank = [dt]
+    if world > 1:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        allt = [torch.zeros_like(t) for _ in range(world)]
+        dist.all_gather(allt, t)
+        per_rank = [float(v.item()) for v in allt]
+        dt = max(per_rank)
+    return dt, per_rank, y
+
+
+def conv_roofline(ops, steps, alg_gf_step, prefer_dtype, batch=None, precision=None):
+    """roofline of the dominant conv kernel from the live HIP events of the timed steps (events are recorded on the launch
+    stream around every conv launch; the kernel each launch resolved to comes from mnet_conv2d_plan)"""
+    per = {}
+    for s_, e_, fl, dt_, kid in ops.stats.events:
+        r = per.setdefault((kid, dt_), [0.0, 0.0, 0])
+        r[0] += s_.elapsed_time(e_); r[1] += fl; r[2] += 1
+    cand = {k: v for k, v in per.items() if k[1] == prefer_dtype} or per
+    dom = max(cand, key=lambda k: cand[k][0])
+    dom_ms, dom_fl, dom_n = cand[dom]
+    peak = DTPEAK[dom[1]]
+    achieved = dom_fl / max(dom_ms, 1e-9) / 1e9                        # FLOP/ms/1e9 == TFLOP/s (algorithmic FLOPs)
+    main_ms = sum(v[0] for k, v in per.items() if k[1] == prefer_dtype) / max(steps, 1)
+    all_ms = sum(v[0] for v in per.values()) / max(steps, 1)
+    kname = KNAME.get(dom[0], str(dom[0]))
+    traffic, traffic_note = None, None
+    tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")        # measured separately (rocprofv3 --pmc passes), see DESIGN.md
+    if os.path.isfile(tpath):
+        try:
+            tj = json.load(open(tpath))
+            ent = tj.get(kname + (" " + DTNAME[dom[1]] if dom[1] == 2 else ""), tj.get(kname, {}))
+            if tj.get("kernel_sources_sha16") == kernel_sources_sha() and tj.get("batch") == batch and tj.get("precision") == precision:
+                traffic = ent.get("hbm_bytes_per_launch")
+                traffic_note = "rocprofv3 --pmc passes of this bench at %s (profiles/pmc_traffic.json), kernel sources unchanged since" % tj.get("measured_at", "?")
+            else:
+                traffic_note = ("profiles/pmc_traffic.json was measured on other kernel sources or another batch / precision "
+                                "(%s, batch %s, %s): not reported" % (tj.get("measured_at", "round 1"), tj.get("batch", 64), tj.get("precision", "fp16")))
+        except Exception as e:      # noqa: BLE001
+            traffic_note = "profiles/pmc_traffic.json unreadable: %s" % e
+    return {
+        "bound": "mfma", "achieved": round(achieved, 2), "peak": round(peak, 1), "unit": "TFLOP/s",
+        "frac": round(achieved / peak, 4), "traffic": traffic, "traffic_source": traffic_note,
+        "kernel": kname + " " + DTNAME[dom[1]],
+        "launches_per_step": dom_n // max(steps, 1),
+        "avg_launch_ms": round(dom_ms / max(dom_n, 1), 4),
+        "flops_per_launch_avg": round(dom_fl / max(dom_n, 1), 1),
+        "kernel_ms_per_step": round(dom_ms / max(steps, 1), 3),
+        "all_conv_kernels": {
+            "achieved": round(alg_gf_step / max(main_ms, 1e-9), 2), "frac": round(alg_gf_step / max(main_ms, 1e-9) / peak, 4),
+            "ms_per_step": round(main_ms, 3), "ms_per_step_all_dtypes": round(all_ms, 3),
+            "algorithmic_gflop_per_step": round(alg_gf_step, 1),
+            "launched_gflop_per_step": round(sum(v[1] for v in per.values()) / max(steps, 1) / 1e9, 1),
+            "by_kernel_ms_per_step": {KNAME.get(k[0], str(k[0])) + " " + DTNAME[k[1]]: round(v[0] / max(steps, 1), 3)
+                                      for k, v in sorted(per.items())},
+        },
+    }, peak
 
 
 def main():
@@ -57,41 +163,23 @@ def main():
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         dist.init_process_group("nccl", device_id=dev)
-
-    if world > 1:       # N ranks build the same seeded checkpoints on the host at the same time: do not oversubscribe its cores
-        try:
-            avail = len(os.sched_getaffinity(0))
-        except AttributeError:
-            avail = os.cpu_count() or 1
-        torch.set_num_threads(max(1, min(32, avail // world)))
+        # N ranks build the same seeded checkpoints on the host at the same time: do not oversubscribe its cores
+        torch.set_num_threads(max(1, min(32, host_threads(1 << 30) // world)))
 
     from marconet_amd import networks, ops, synthetic
-    from marconet_amd.pipeline import MarconetPipeline, OverlappedGather
+    from marconet_amd.pipeline import MarconetPipeline, OverlappedGather, balance_shards
 
     sde, sdg, sds = synthetic.make_encoder_state_dict(), synthetic.make_gan_state_dict(), synthetic.make_sr_state_dict()
     enc, gan, sr = networks.TextContextEncoderV2(), networks.TSPGAN(), networks.TSPSRNet()
     enc.load_state_dict(sde, strict=True)
     gan.load_state_dict(sdg, strict=True)
     sr.load_state_dict(sds, strict=True)
-    pipe = MarconetPipeline(enc.eval().to(dev), gan.eval().to(dev), sr.eval().to(dev), precision=a.precision)
+    pipe = MarconetPipeline(enc.eval().to(dev), gan.eval().to(dev), sr.eval().to(dev), precision=a.precision, check_finite=False)
+    pdt = {"fp32": 0, "fp16": 1, "fp16x3": 2}[a.precision]
 
     B, n = a.batch, a.glyphs
-    widths = [512] * B
-    lq = synthetic.make_lq(1234 + rank, B, widths).to(dev)
-    # labels and glyph locations stay on the HOST, where the OCR / detector front-end leaves them (test_sr.py:121-149):
-    # the forward then needs no device→host synchronisation at all
-    labels = [synthetic.make_labels(1234 + 1000 * rank + b, n) for b in range(B)]
-    locs = synthetic.make_locs([n] * B, widths)
-
-    gather = OverlappedGather() if world > 1 and not a.no_gather else None
-
-    def step():
-        # N > 1: the all-gather of this step's SR outputs (the one collective of the path) is enqueued asynchronously and
-        # overlaps the next step's compute; the fence below waits for the last one, so every gather is inside the timed region
-        y = pipe.forward_batch(lq, labels, locs)
-        if gather is not None:
-            gather.submit(y)
-        return y
+    gather = OverlappedGather() if world > 1 and not a.no_gather and a.config != "gan" else None
+    u8 = gather is not None and a.gather_format == "u8"
 
     def fence():
         if gather is not None:
@@ -101,132 +189,137 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    secondary = None
+    # ------------------------------------------------------------------ workload
+    if a.config == "sr":
+        widths = [512] * B
+        lq = synthetic.make_lq(1234 + rank, B, widths).to(dev)
+        # labels and glyph locations stay on the HOST, where the OCR / detector front-end leaves them (test_sr.py:121-149):
+        # the forward then needs no device→host synchronisation at all
+        labels = [synthetic.make_labels(1234 + 1000 * rank + b, n) for b in range(B)]
+        locs = synthetic.make_locs([n] * B, widths)
+        images_per_step = B
+        alg_gf_step = B * (GF_F16_FIXED + GF_F16_PER_GLYPH * n)       # algorithmic GFLOP of the non-ViT convs per step
+        gf_image = GF_F16_FIXED + GF_F16_PER_GLYPH * n + GF_VIT
+        workload = ("BASELINE.json metric configuration: batch %d synthetic 32x512 LR strips per GPU, %d glyphs/image, %s, "
+                    "encoder+TSPGAN+TSPSRNet, seeded random-init checkpoints" % (B, n, a.precision))
+
+        def step():
+            # N > 1: the all-gather of this step's outputs (the one collective of the path) is enqueued asynchronously and
+            # overlaps the next step's compute; the fence waits for the last one, so every gather is inside the timed region
+            y = pipe.forward_batch(lq, labels, locs, output="u8_bgr" if u8 else "nchw_f32")
+            if gather is not None:
+                gather.submit(y)
+            return y
+    elif a.config == "gan":
+        N = B * n                                                     # configs[3]: 256 x 16 = 4096 glyph images per step
+        styles = synthetic.make_styles(77 + rank, N).to(dev)
+        glabels = synthetic.make_labels(78 + rank, N).to(dev)
+        gan.set_precision(a.precision)
+        images_per_step = N
+        alg_gf_step = N * GF_GAN
+        gf_image = GF_GAN
+        workload = ("BASELINE.json configs[3]: test_w.py StyleGAN-prior path alone, %d x %d = %d glyph images (128x128) per GPU per "
+                    "step through TSPGAN in chunks of %d, random styles, %s" % (B, n, N, pipe.glyph_chunk, a.precision))
+
+        def step():
+            y = None
+            for s in range(0, N, pipe.glyph_chunk):                   # bounded working set (8.6 GB of 128-px maps per 1024 glyphs)
+                y = gan(styles=styles[s:s + pipe.glyph_chunk], labels=glabels[s:s + pipe.glyph_chunk], noise=None)[0]
+            return y
+    else:
+        # configs[4]: content widths uniform in {128,192,...,512}; n_b = w_b / 32 glyphs; the GLOBAL batch (B x world strips,
+        # same on every rank) is split by algorithmic work (pipeline.balance_shards), each rank runs its strips bucketed by width
+        G = B * world
+        wsel = synthetic.integers(4321, "mixed.w", (G,), 0, 7).tolist()
+        widths_all = [128 + 64 * int(v) for v in wsel]
+        counts_all = [w_ // 32 for w_ in widths_all]
+        mine = balance_shards(widths_all, counts_all, world)[rank]
+        widths = [widths_all[i] for i in mine]
+        counts = [counts_all[i] for i in mine]
+        lq = synthetic.make_lq(4000 + rank, len(mine), widths).to(dev)
+        labels = [synthetic.make_labels(4100 + i, c) for i, c in zip(mine, counts)]
+        locs = synthetic.make_locs(counts, widths, max_glyphs=16)
+        images_per_step = len(mine)
+        alg_gf_step = sum(GF_RESNET + GF_SR_TRUNK * w_ / 512.0 + GF_F16_PER_GLYPH * c for w_, c in zip(widths, counts))
+        gf_image = (alg_gf_step + GF_VIT * len(mine)) / max(len(mine), 1)
+        workload = ("BASELINE.json configs[4]: %d strips per GPU of content width uniform in {128..512 step 64}, w/32 glyphs each, "
+                    "bucketed by padded width (64-px buckets), work-balanced shards, %s" % (B, a.precision))
+
+        def step():
+            outs = pipe.forward_mixed_widths(lq, widths, labels, locs)
+            return outs[-1]
+
     for _ in range(a.warmup):
         step()
     ops.stats.reset()
     ops.stats.enabled = ops.stats.timing = True          # HIP events around every conv launch (same stream)
-    fence()
-    t0 = time.perf_counter()
-    for _ in range(a.steps):
-        y = step()
-    fence()
-    dt = time.perf_counter() - t0
+    dt, per_rank_dt, y = timed(step, fence, a.steps, world, dev)
     ops.stats.enabled = ops.stats.timing = False
+    if y.dtype.is_floating_point:
+        assert torch.isfinite(y).all()
+    total_images = images_per_step
     if world > 1:
-        t = torch.tensor([dt], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
-    assert torch.isfinite(y).all()
+        t = torch.tensor([images_per_step], device=dev, dtype=torch.float64)
+        dist.all_reduce(t)
+        total_images = int(t.item())
+    roofline, peak = conv_roofline(ops, a.steps, alg_gf_step, pdt, B if a.config == "sr" else None, a.precision)
 
-    # ---- secondary figure (reported separately, never the headline): the same step without the generator's 128-px
-    # structure image, which only feeds test_sr.py's saved visualisation (SURVEY.md §7 "hard parts", last item)
-    secondary = None
-    prec16 = a.precision == "fp16"
-    if not a.no_secondary:
+    # ---- secondary figures (reported separately, never the headline)
+    if a.config == "sr" and not a.no_secondary:
+        # the same step without the generator's 128-px structure image, which only feeds test_sr.py's saved visualisation
         pipe.need_prior_image = False
         step()
-        fence()
-        t0 = time.perf_counter()
-        for _ in range(a.steps):
-            step()
-        fence()
-        dt2 = time.perf_counter() - t0
+        dt2, _, _ = timed(step, fence, a.steps, world, dev)
         pipe.need_prior_image = True
-        if world > 1:
-            t = torch.tensor([dt2], device=dev, dtype=torch.float64)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            dt2 = float(t.item())
-        secondary = {"images_per_s_without_prior_image": round(B * world * a.steps / dt2, 3), "ms_per_step": round(dt2 / a.steps * 1e3, 3),
+        secondary = {"images_per_s_without_prior_image": round(total_images * a.steps / dt2, 3), "ms_per_step": round(dt2 / a.steps * 1e3, 3),
                      "note": "opt-in MarconetPipeline(need_prior_image=False): TSPGAN stops at the 64-px level; SR output identical"}
-        if world == 1 and prec16:
-            # the fp32 parity mode (<= 1e-3 vs the reference, bit-exact indices: see "parity" below) on a 16-image slice
+        if world == 1:
             kb = min(B, 16)
-            pipe.set_precision("fp32")
-            pipe.forward_batch(lq[:kb], labels[:kb], locs[:kb])
-            torch.cuda.synchronize()
-            t0 = time.perf_counter()
-            pipe.forward_batch(lq[:kb], labels[:kb], locs[:kb])
-            torch.cuda.synchronize()
-            secondary["fp32_parity_mode_images_per_s"] = round(kb / (time.perf_counter() - t0), 3)
-            secondary["fp32_parity_mode_batch"] = kb
+            for prec in ("fp16", "fp16x3", "fp32"):
+                if prec == a.precision:
+                    continue
+                try:
+                    pipe.set_precision(prec)
+                except ValueError:
+                    continue
+                kk = kb if prec == "fp32" else min(B, 64)
+                pipe.forward_batch(lq[:kk], labels[:kk], locs[:kk])
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                pipe.forward_batch(lq[:kk], labels[:kk], locs[:kk])
+                torch.cuda.synchronize()
+                secondary["%s_mode_images_per_s" % prec] = round(kk / (time.perf_counter() - t0), 3)
+                secondary["%s_mode_batch" % prec] = kk
             pipe.set_precision(a.precision)
 
-    # ---- roofline of the dominant kernel, from the live HIP events of the timed steps (events are recorded on the
-    # launch stream around every conv launch; the kernel each launch resolved to comes from mnet_conv2d_plan)
-    KNAME = {1: "conv_igemm_kernel (register-staged)", 3: "conv_skinny_f32_kernel", 16: "conv_dma_kernel<256,256,4,4,2,16>", 17: "conv_dma_kernel<256,128,4,2,3,16>",
-             18: "conv_dma_kernel<128,256,2,4,3,16>", 19: "conv_dma_kernel<64,256,1,8,3,16>", 20: "conv_dma_kernel<128,512,2,8,2,16>",
-             21: "conv_dma_kernel<64,512,1,8,2,16>", 22: "conv_dma_kernel<256,256,2,4,2,16>", 26: "conv_dma_kernel<128,128,2,4,4,16>",
-             32: "conv_strip_kernel<256,256,4,4>", 33: "conv_strip_kernel<64,512,1,8>", 34: "conv_strip_kernel<128,256,2,4>"}
-    per = {}
-    for s_, e_, fl, dt_, kid in ops.stats.events:
-        key = (kid, dt_)
-        ms = s_.elapsed_time(e_)
-        r = per.setdefault(key, [0.0, 0.0, 0])
-        r[0] += ms; r[1] += fl; r[2] += 1
-    prec16 = a.precision == "fp16"
-    cand = {k: v for k, v in per.items() if k[1] == (1 if prec16 else 0)}
-    dom = max(cand, key=lambda k: cand[k][0])
-    dom_ms, dom_fl, dom_n = cand[dom]
-    f16_ms = sum(v[0] for k, v in per.items() if k[1] == 1)
-    f32_ms = sum(v[0] for k, v in per.items() if k[1] == 0)
-    f16_n = sum(v[2] for k, v in per.items() if k[1] == 1)
-    f16_fl = sum(v[1] for k, v in per.items() if k[1] == 1)
-    alg_gf_step = B * (GF_F16_FIXED + GF_F16_PER_GLYPH * n)           # algorithmic GFLOP of the f16 convs per step
-    peak = PEAK_F16_TFLOPS if prec16 else 157.3
-    achieved = dom_fl / max(dom_ms, 1e-9) / 1e9                        # FLOP/ms/1e9 == TFLOP/s
-    conv_ms = (f16_ms if prec16 else f16_ms + f32_ms) / max(a.steps, 1)
-    traffic = None
-    tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")        # measured separately (rocprofv3 --pmc), see DESIGN.md
-    if os.path.isfile(tpath):
-        try:
-            traffic = json.load(open(tpath)).get(KNAME.get(dom[0], ""), {}).get("hbm_bytes_per_launch")
-        except Exception:
-            traffic = None
-    roofline = {
-        "bound": "mfma", "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
-        "frac": round(achieved / peak, 4), "traffic": traffic,
-        "kernel": KNAME.get(dom[0], str(dom[0])) + (" f16" if dom[1] == 1 else " f32"),
-        "launches_per_step": dom_n // max(a.steps, 1),
-        "avg_launch_ms": round(dom_ms / max(dom_n, 1), 4),
-        "flops_per_launch_avg": round(dom_fl / max(dom_n, 1), 1),
-        "kernel_ms_per_step": round(dom_ms / max(a.steps, 1), 3),
-        "all_conv_kernels": {
-            "achieved": round(alg_gf_step / max(conv_ms, 1e-9), 2), "frac": round(alg_gf_step / max(conv_ms, 1e-9) / peak, 4),
-            "launches_per_step": f16_n // max(a.steps, 1), "ms_per_step": round(conv_ms, 3),
-            "algorithmic_gflop_per_step": round(alg_gf_step, 1),
-            "launched_gflop_per_step": round(f16_fl / max(a.steps, 1) / 1e9, 1),
-            "by_kernel_ms_per_step": {KNAME.get(k[0], str(k[0])) + (" f16" if k[1] else " f32"): round(v[0] / max(a.steps, 1), 3)
-                                      for k, v in sorted(per.items())},
-        },
-        "end_to_end_frac_of_peak": None,
-    }
-
     out = {
-        "metric": "SR images/sec (32x512 LR -> 128x2048 SR)", "value": round(B * world * a.steps / dt, 3),
+        "metric": {"sr": "SR images/sec (32x512 LR -> 128x2048 SR)", "gan": "TSPGAN glyph images/sec (128x128 structure prior)",
+                   "mixed": "SR images/sec (mixed-width 32x{128..512} LR, bucketed)"}[a.config],
+        "value": round(total_images * a.steps / dt, 3),
         "unit": "images/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
         "ms_per_step": round(dt / a.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
-        "vs_baseline": None, "dtype": "f16" if prec16 else "f32", "data": "synthetic",
-        "config": {"workload": "BASELINE.json configs[1]: batch %d synthetic 32x512 LR strips per GPU, %d glyphs/image, "
-                               "%s storage + fp32 accumulate, encoder+TSPGAN+TSPSRNet, seeded random-init checkpoints"
-                               % (B, n, a.precision),
-                   "per_gpu_batch": B, "global_batch": B * world, "glyphs_per_image": n,
-                   "parallelism": "dp%d" % world, "collective": "all_gather(SR outputs), asynchronous, overlapped with the next step" if world > 1 and not a.no_gather else "none"},
+        "vs_baseline": None, "dtype": DTNAME[pdt], "data": "synthetic",
+        "config": {"workload": workload, "per_gpu_batch": B, "global_batch": total_images, "glyphs_per_image": n,
+                   "parallelism": "dp%d" % world,
+                   "collective": ("all_gather(%s), asynchronous, overlapped with the next step"
+                                  % ("uint8 BGR post-processed SR [b,128,2048,3]" if u8 else "fp32 SR outputs [b,3,128,2048]"))
+                   if gather is not None else "none"},
         "roofline": roofline,
         "secondary": secondary,
     }
-    roofline["end_to_end_frac_of_peak"] = round(out["value"] / world * (GF_F16_FIXED + GF_F16_PER_GLYPH * n + GF_FP32_VIT) / 1e3 / peak, 4)
+    roofline["end_to_end_frac_of_peak"] = round(out["value"] / world * gf_image / 1e3 / peak, 4)
+    if world > 1:
+        out["ranks"] = {"world_size": dist.get_world_size(), "backend": dist.get_backend(),
+                        "per_rank_images_per_s": [round(images_per_step * a.steps / t_, 2) for t_ in per_rank_dt]}
 
     # ---- CPU baseline (the oracle = port of the reference's CPU forward) + parity, rank 0 at N=1 only
-    if rank == 0 and world == 1 and a.cpu_images > 0:
+    if rank == 0 and world == 1 and a.cpu_images > 0 and a.config == "sr":
         from oracle import marconet_oracle as O
         k = a.cpu_images
         # the threads actually used: the affinity mask, capped (oneDNN convs at batch 1 stop scaling well before
         # that, and 256 oversubscribed threads on a cgroup-limited box measured 100x slower)
-        try:
-            avail = len(os.sched_getaffinity(0))
-        except AttributeError:
-            avail = os.cpu_count() or 1
-        threads = max(1, min(avail, a.cpu_threads))
+        threads = host_threads(a.cpu_threads)
         torch.set_num_threads(threads)
         lq_c, locs_c = lq[:k].cpu(), locs[:k]
         lab_c = labels[:k]
@@ -238,15 +331,35 @@ def main():
                                "sample": "%d images (batch 1 each, %d glyphs) of the same workload through oracle/marconet_oracle.py, "
                                          "torch %s CPU fp32, %d threads" % (k, n, torch.__version__, threads)}
         ref_sr = torch.cat([r["sr"] for r in refs])
+        ref_arg = torch.cat([r["logits"] for r in refs]).argmax(-1)
         par = {}
-        for prec in ("fp16", "fp32"):
-            pipe.set_precision(prec)
+        for prec in ("fp16", "fp16x3", "fp32"):
+            try:
+                pipe.set_precision(prec)
+            except ValueError:
+                continue
             yk = pipe.forward_batch(lq[:k], labels[:k], locs[:k])
             lg = pipe.encoder(lq[:k])[0]
             par["sr_max_abs_%s" % prec] = round((yk.cpu() - ref_sr).abs().max().item(), 6)
-            par["argmax_match_%s" % prec] = round(float((lg.argmax(-1).cpu() == torch.cat([r["logits"] for r in refs]).argmax(-1)).float().mean()), 4)
+            par["argmax_match_%s" % prec] = round(float((lg.argmax(-1).cpu() == ref_arg).float().mean()), 4)
         pipe.set_precision(a.precision)
+        par["bar"] = "north_star: <= 1e-3 max-abs on the SR output, argmax bit-exact (argmax_match == 1.0)"
         out["parity"] = par
+    elif rank == 0 and world == 1 and a.cpu_images > 0 and a.config == "gan":
+        from oracle import marconet_oracle as O
+        threads = host_threads(a.cpu_threads)
+        torch.set_num_threads(threads)
+        k = min(16, styles.shape[0])
+        st_c, lab_c = styles[:k].cpu(), glabels[:k].cpu()
+        O.tspgan_forward(sdg, st_c[:2], lab_c[:2])
+        t0 = time.perf_counter()
+        ref = O.tspgan_forward(sdg, st_c, lab_c)
+        cdt = time.perf_counter() - t0
+        out["cpu_baseline"] = {"value": round(k / cdt, 4), "unit": "images/s", "cores": threads, "kind": "port",
+                               "sample": "%d glyphs in one TSPGAN call through oracle/marconet_oracle.py, torch %s CPU fp32, %d threads" % (k, torch.__version__, threads)}
+        yk = gan(styles=styles[:k], labels=glabels[:k], noise=None)
+        out["parity"] = {"image_max_abs_%s" % a.precision: round((yk[0].cpu() - ref[0]).abs().max().item(), 6),
+                         "prior64_max_abs_%s" % a.precision: round((yk[1].cpu() - ref[1]).abs().max().item(), 6)}
 
     if rank == 0:
         print(json.dumps(out))

@@ -163,6 +163,27 @@ class MarconetPipeline:
 
 
     @torch.no_grad()
+    def forward_sharded(self, lq, labels, locs, output="u8_bgr", group=None):
+        """Data-parallel form of forward_batch: every rank of the process group (one process per GPU; backend
+        'nccl' = RCCL over xGMI) is handed the SAME global batch description (lq [B,3,32,512] on the host or on the rank's
+        device, labels list, locs [B,2m]), processes its contiguous shard ``shard_range(B, rank, world)`` and all-gathers the
+        outputs — the one collective of the path; by default the post-processed uint8 BGR image (0.75 MiB per image instead of
+        the 3 MiB fp32 tensor).  → [B,128,2048,3] uint8 (or [B,3,128,2048] fp32 for output="nchw_f32") on every rank, equal
+        bit for bit to a single-GPU forward_batch of the whole batch (kernels are batch-invariant)."""
+        import torch.distributed as dist
+        world = dist.get_world_size(group) if dist.is_initialized() else 1
+        rank = dist.get_rank(group) if dist.is_initialized() else 0
+        B = lq.shape[0]
+        a, b = shard_range(B, rank, world)
+        dev = next(self.sr.parameters()).device
+        if b > a:
+            y = self.forward_batch(lq[a:b].to(dev), labels[a:b], locs[a:b], output=output)
+        else:                         # more ranks than images: an empty shard still takes part in the collective
+            shape = (0, 128, 4 * lq.shape[3], 3) if output == "u8_bgr" else (0, 3, 128, 4 * lq.shape[3])
+            y = torch.empty(shape, dtype=torch.uint8 if output == "u8_bgr" else torch.float32, device=dev)
+        return y if world == 1 else all_gather_outputs(y, B, group)
+
+    @torch.no_grad()
     def restore_strips(self, strips):
         """The body of test_sr.py's ``for img_name`` loop (:77-201) for a list of strips prepared by ``lq_io.strip_from_png``
         (dicts with lq [1,3,32,512], labels int64 [n,1], locs [1,2n], show_w) — as ONE batch.  → list of uint8 BGR arrays

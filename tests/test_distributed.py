@@ -69,6 +69,59 @@ def test_all_gather_outputs_world2_gloo(total):
         assert equal, "rank %d: gathered outputs differ from the 1-process result" % rank
 
 
+class _HostPipe:
+    """MarconetPipeline.forward_sharded over a stand-in forward_batch (a deterministic function of each image alone), so that the
+    real sharding / empty-shard / gather logic of the product driver runs on CPU"""
+
+    def __init__(self):
+        from marconet_amd.pipeline import MarconetPipeline
+        self.sr = torch.nn.Linear(1, 1)                       # forward_sharded only asks it for a device
+        self.forward_sharded = MarconetPipeline.forward_sharded.__get__(self)
+
+    def forward_batch(self, lq, labels, locs, output="u8_bgr"):
+        y = (lq.sum(dim=(1, 2, 3)) + torch.tensor([float(l.sum()) for l in labels]) + locs.sum(dim=1)).reshape(-1, 1, 1, 1)
+        shape = (lq.shape[0], 128, 4 * lq.shape[3], 3) if output == "u8_bgr" else (lq.shape[0], 3, 128, 4 * lq.shape[3])
+        y = y.expand(shape)
+        return (y.abs() % 255).to(torch.uint8).contiguous() if output == "u8_bgr" else y.float().contiguous()
+
+
+def _sharded_worker(rank, world, port, total, out_q):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        g = torch.Generator().manual_seed(7)
+        lq = torch.rand((total, 3, 4, 16), generator=g)
+        labels = [torch.arange(i % 3).reshape(-1, 1) for i in range(total)]
+        locs = torch.rand((total, 4), generator=g)
+        pipe = _HostPipe()
+        ok = True
+        for output in ("u8_bgr", "nchw_f32"):
+            full = pipe.forward_sharded(lq, labels, locs, output=output)
+            ok = ok and bool(torch.equal(full, pipe.forward_batch(lq, labels, locs, output=output)))
+        out_q.put((rank, ok))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("total", [6, 5, 1])
+def test_forward_sharded_world2_gloo(total):
+    """the product's data-parallel driver (MarconetPipeline.forward_sharded): contiguous shards, an empty shard when there
+    are more ranks than images, uint8 / fp32 gather — every rank ends with the single-process result"""
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_sharded_worker, args=(r, world, port, total, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert all(ok for _, ok in res)
+
+
 def test_shard_range_partitions_exactly():
     from marconet_amd.pipeline import shard_range
     for total in (0, 1, 5, 64, 1024, 1027):

@@ -186,7 +186,7 @@ def test_fp16_throughput_mode_deviation(nets, ckpts):
         _note("sr.fp16.grid.chain.maxabs", e)
         _note("sr.fp16.grid.chain.meanabs", (y.cpu() - r["sr"]).abs().mean().item())
         assert torch.isfinite(y).all()
-        assert e <= 0.1
+        assert e <= 2.5e-2          # plain fp16 storage measures 1.1e-2 - 1.2e-2 here: a 2x regression fails
     finally:
         for m in nets:
             m.set_precision("fp32")
@@ -345,6 +345,27 @@ def test_full_size_batch_properties_fp16(nets):
         assert torch.equal(shuffled, full.index_select(0, pt))
     finally:
         pipe.set_precision("fp32")
+
+
+def test_forward_batch_vs_oracle_on_bench_shaped_strips(nets, ckpts):
+    """the batched driver (what bench.py times) against the CPU oracle on 4 strips of the bench shape — full 512-px width,
+    ragged glyph counts up to the bench's 16 per image — in the fp32 parity mode: <= 1e-3, indices bit-exact"""
+    from marconet_amd.pipeline import MarconetPipeline
+    counts = [16, 9, 0, 13]
+    widths = [512, 512, 512, 470]
+    lq = synth.make_lq(131, 4, widths)
+    labels = [synth.make_labels(140 + b, c) for b, c in enumerate(counts)]
+    locs = synth.make_locs(counts, widths, max_glyphs=16)
+    pipe = MarconetPipeline(*nets, precision="fp32")
+    y = pipe.forward_batch(lq.to(DEV), labels, locs)                      # labels / locs on the host, like bench.py
+    logits = nets[0](lq.to(DEV))[0]
+    worst = 0.0
+    for b in range(4):
+        r = O.end_to_end(ckpts[0], ckpts[1], ckpts[2], lq[b:b + 1], [labels[b]], locs[b:b + 1])      # batch 1, like test_sr.py:77
+        worst = max(worst, _err(y[b:b + 1], r["sr"]))
+        assert torch.equal(logits[b:b + 1].argmax(-1).cpu(), r["logits"].argmax(-1))
+    _note("sr.fp32.forward_batch.bench_shape.maxabs", worst)
+    assert worst <= TOL
 
 
 def test_generator_distinct_styles_equal_expanded(nets):

@@ -1,0 +1,40 @@
+"""-m gpu, needs >= 2 visible MI355X (skipped on the 1-GPU box): N-GPU gathered output == 1-GPU output, bit for bit, through
+the real pipeline over RCCL (SURVEY.md §8e correctness test)."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+@pytest.mark.parametrize("total", [5, 2])
+def test_sharded_forward_equals_single_gpu(total, tmp_path):
+    world = 2
+    if torch.cuda.device_count() < world:
+        pytest.skip("needs %d GPUs, %d visible" % (world, torch.cuda.device_count()))
+    port, out = _free_port(), str(tmp_path / "res.json")
+    procs = []
+    for r in range(world):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), LOCAL_RANK=str(r), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "dist_pipeline_worker.py"), out, str(total)], env=env))
+    for p in procs:
+        assert p.wait(timeout=900) == 0
+    res = json.load(open(out))
+    assert res["world"] == world and res["backend"] == "nccl"
+    for k in ("fp32.u8_bgr", "fp32.nchw_f32", "fp16.u8_bgr", "fp16.nchw_f32"):
+        assert res[k], "%s: gathered result differs from the single-GPU result" % k
