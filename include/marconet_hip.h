@@ -26,9 +26,15 @@
 extern "C" {
 #endif
 
-#define MNET_ABI_VERSION 1
+#define MNET_ABI_VERSION 2
 
-typedef enum { MNET_F32 = 0, MNET_F16 = 1 } mnet_dtype;
+/* MNET_F16X2 ("split half", the storage of the fp16x3 precision mode): every logical element is a pair of halves (hi, lo),
+ * value = float(hi) + float(lo), hi = f16(v), lo = f16(v - hi): ~22 significant bits at fp16 MFMA rates (x*w is evaluated as
+ * hi*hi + hi*lo + lo*hi, fp32 accumulate) — the throughput mode that meets the 1e-3 parity bar.  NHWC layout [.., C] with
+ * C % 32 == 0 and a 128-byte aligned base: per pixel 4*C bytes in blocks of 32 channels, 64 bytes of hi followed by 64 bytes
+ * of lo.  Conv weights [cout][kh][kw][cin] use the same blocking along cin and hold hi/lo of 256*W (the conv multiplies its
+ * accumulator by 2^-8).  Entry points that accept it say so; sizes/strides are always given in LOGICAL elements. */
+typedef enum { MNET_F32 = 0, MNET_F16 = 1, MNET_F16X2 = 2 } mnet_dtype;
 
 typedef enum {
     MNET_ACT_NONE = 0,

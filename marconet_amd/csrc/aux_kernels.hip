@@ -22,7 +22,7 @@ __global__ void __launch_bounds__(256) nchw_to_nhwc_kernel(const float* __restri
     T* d = dst + (size_t)n * HW * Cld;
     for (int j = ty; j < 32; j += 8) {
         const int p = p0 + j, c = c0 + tx;
-        if (p < HW && c < Cld) d[(size_t)p * Cld + c] = (T)tile[tx][j];
+        if (p < HW && c < Cld) st_elem<T>(d + (size_t)p * Cld, c, tile[tx][j]);
     }
 }
 
@@ -35,7 +35,7 @@ __global__ void __launch_bounds__(256) nhwc_to_nchw_kernel(const T* __restrict__
     const T* s = src + (size_t)n * HW * Cld;
     for (int j = ty; j < 32; j += 8) {
         const int p = p0 + j, c = c0 + tx;
-        tile[j][tx] = (p < HW && c < C) ? (float)s[(size_t)p * Cld + c] : 0.f;
+        tile[j][tx] = (p < HW && c < C) ? ld_elem<T>(s + (size_t)p * Cld, c) : 0.f;
     }
     __syncthreads();
     float* d = dst + (size_t)n * C * HW;
@@ -48,12 +48,14 @@ __global__ void __launch_bounds__(256) nhwc_to_nchw_kernel(const T* __restrict__
 extern "C" int mnet_nchw_to_nhwc(const float* src, void* dst, int32_t dst_dtype, int32_t n, int32_t c, int32_t h,
                                  int32_t w, int32_t c_ld, void* stream) {
     MNET_CHECK_ARG(src && dst && n > 0 && c > 0 && h > 0 && w > 0 && c_ld >= c, "nchw_to_nhwc: bad args");
-    MNET_CHECK_ARG(dst_dtype == MNET_F32 || dst_dtype == MNET_F16, "nchw_to_nhwc: bad dtype");
+    MNET_CHECK_ARG(dst_dtype == MNET_F32 || dst_dtype == MNET_F16 || dst_dtype == MNET_F16X2, "nchw_to_nhwc: bad dtype");
+    MNET_CHECK_ALIGN(dst_dtype != MNET_F16X2 || (c_ld % 32 == 0 && aligned128(dst)), "nchw_to_nhwc: split-half output needs c_ld %% 32 == 0 and a 128-byte aligned base");
     MNET_CHECK_ARG(n <= 65535 && (c_ld + 31) / 32 <= 65535, "nchw_to_nhwc: grid too large");
     const int HW = h * w;
     dim3 grid((HW + 31) / 32, (c_ld + 31) / 32, n), block(32, 8);
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     if (dst_dtype == MNET_F16) hipLaunchKernelGGL(nchw_to_nhwc_kernel<f16>, grid, block, 0, st, src, (f16*)dst, c, HW, c_ld);
+    else if (dst_dtype == MNET_F16X2) hipLaunchKernelGGL(nchw_to_nhwc_kernel<hs>, grid, block, 0, st, src, (hs*)dst, c, HW, c_ld);
     else hipLaunchKernelGGL(nchw_to_nhwc_kernel<float>, grid, block, 0, st, src, (float*)dst, c, HW, c_ld);
     MNET_LAUNCH_CHECK("nchw_to_nhwc");
     return MNET_OK;
@@ -62,12 +64,14 @@ extern "C" int mnet_nchw_to_nhwc(const float* src, void* dst, int32_t dst_dtype,
 extern "C" int mnet_nhwc_to_nchw(const void* src, int32_t src_dtype, float* dst, int32_t n, int32_t c, int32_t h,
                                  int32_t w, int32_t c_ld, void* stream) {
     MNET_CHECK_ARG(src && dst && n > 0 && c > 0 && h > 0 && w > 0 && c_ld >= c, "nhwc_to_nchw: bad args");
-    MNET_CHECK_ARG(src_dtype == MNET_F32 || src_dtype == MNET_F16, "nhwc_to_nchw: bad dtype");
+    MNET_CHECK_ARG(src_dtype == MNET_F32 || src_dtype == MNET_F16 || src_dtype == MNET_F16X2, "nhwc_to_nchw: bad dtype");
+    MNET_CHECK_ALIGN(src_dtype != MNET_F16X2 || (c_ld % 32 == 0 && aligned128(src)), "nhwc_to_nchw: split-half input needs c_ld %% 32 == 0 and a 128-byte aligned base");
     MNET_CHECK_ARG(n <= 65535 && (c + 31) / 32 <= 65535, "nhwc_to_nchw: grid too large");
     const int HW = h * w;
     dim3 grid((HW + 31) / 32, (c + 31) / 32, n), block(32, 8);
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     if (src_dtype == MNET_F16) hipLaunchKernelGGL(nhwc_to_nchw_kernel<f16>, grid, block, 0, st, (const f16*)src, dst, c, HW, c_ld);
+    else if (src_dtype == MNET_F16X2) hipLaunchKernelGGL(nhwc_to_nchw_kernel<hs>, grid, block, 0, st, (const hs*)src, dst, c, HW, c_ld);
     else hipLaunchKernelGGL(nhwc_to_nchw_kernel<float>, grid, block, 0, st, (const float*)src, dst, c, HW, c_ld);
     MNET_LAUNCH_CHECK("nhwc_to_nchw");
     return MNET_OK;
@@ -100,9 +104,9 @@ __global__ void __launch_bounds__(256) upsample2x_kernel(const T* __restrict__ s
         for (int r = 0; r < 3; ++r) {
             float a[N], b[N], c[N];
             const T* rp = base + (size_t)rows[r] * W * C;
-            Vec<T>::unpack(ldg16(rp + (size_t)xm * C), a);
-            Vec<T>::unpack(ldg16(rp + (size_t)x * C), b);
-            Vec<T>::unpack(ldg16(rp + (size_t)xp * C), c);
+            unpackr<T>(ldraw<T>(rp + (size_t)xm * C), a);
+            unpackr<T>(ldraw<T>(rp + (size_t)x * C), b);
+            unpackr<T>(ldraw<T>(rp + (size_t)xp * C), c);
 #pragma unroll
             for (int j = 0; j < N; ++j) { hl[r][j] = 0.25f * a[j] + 0.75f * b[j]; hr[r][j] = 0.75f * b[j] + 0.25f * c[j]; }
         }
@@ -122,30 +126,32 @@ __global__ void __launch_bounds__(256) upsample2x_kernel(const T* __restrict__ s
         const size_t orow = (size_t)2 * W * C;
 #pragma unroll
         for (int j = 0; j < N; ++j) o[j] = (0.25f * hl[0][j] + 0.75f * hl[1][j]) * sc[j];
-        stg16(q, Vec<T>::pack(o));
+        straw<T>(q, packr<T>(o));
 #pragma unroll
         for (int j = 0; j < N; ++j) o[j] = (0.25f * hr[0][j] + 0.75f * hr[1][j]) * sc[j];
-        stg16(q + C, Vec<T>::pack(o));
+        straw<T>(q + C, packr<T>(o));
 #pragma unroll
         for (int j = 0; j < N; ++j) o[j] = (0.75f * hl[1][j] + 0.25f * hl[2][j]) * sc[j];
-        stg16(q + orow, Vec<T>::pack(o));
+        straw<T>(q + orow, packr<T>(o));
 #pragma unroll
         for (int j = 0; j < N; ++j) o[j] = (0.75f * hr[1][j] + 0.25f * hr[2][j]) * sc[j];
-        stg16(q + orow + C, Vec<T>::pack(o));
+        straw<T>(q + orow + C, packr<T>(o));
     }
 }
 
 extern "C" int mnet_upsample2x_scale_nhwc(const void* src, void* dst, int32_t dtype, int32_t n, int32_t h, int32_t w,
                                           int32_t c, const float* scale, void* stream) {
     MNET_CHECK_ARG(src && dst && n > 0 && h > 0 && w > 0 && c > 0 && n <= 65535, "upsample2x: bad args");
-    MNET_CHECK_ARG(dtype == MNET_F32 || dtype == MNET_F16, "upsample2x: bad dtype");
-    const int N = dtype == MNET_F16 ? 8 : 4;
+    MNET_CHECK_ARG(dtype == MNET_F32 || dtype == MNET_F16 || dtype == MNET_F16X2, "upsample2x: bad dtype");
+    const int N = dtype == MNET_F32 ? 4 : 8;
     MNET_CHECK_ALIGN(c % N == 0 && aligned16(src) && aligned16(dst) && aligned16(scale), "upsample2x: c %% %d != 0 or unaligned", N);
+    MNET_CHECK_ALIGN(dtype != MNET_F16X2 || (c % 32 == 0 && aligned128(src) && aligned128(dst)), "upsample2x: split-half needs c %% 32 == 0, 128-byte aligned");
     const long long per = (long long)h * w * (c / N);             // one thread per input chunk
     MNET_CHECK_ARG(per * 4 < (1ll << 31), "upsample2x: image too large");
     const int gx = (int)((per + 255) / 256 < 2048 ? (per + 255) / 256 : 2048);
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     if (dtype == MNET_F16) hipLaunchKernelGGL(upsample2x_kernel<f16>, dim3(gx, n), dim3(256), 0, st, (const f16*)src, (f16*)dst, h, w, c, scale, (unsigned)per);
+    else if (dtype == MNET_F16X2) hipLaunchKernelGGL(upsample2x_kernel<hs>, dim3(gx, n), dim3(256), 0, st, (const hs*)src, (hs*)dst, h, w, c, scale, (unsigned)per);
     else hipLaunchKernelGGL(upsample2x_kernel<float>, dim3(gx, n), dim3(256), 0, st, (const float*)src, (float*)dst, h, w, c, scale, (unsigned)per);
     MNET_LAUNCH_CHECK("upsample2x");
     return MNET_OK;
@@ -178,7 +184,7 @@ __global__ void __launch_bounds__(256) gn_partial_kernel(const T* __restrict__ x
     for (int p = p_begin + pl; p < p_end; p += plane) {
         if ((p % W) >= vw) continue;
         float v[N];
-        Vec<T>::unpack(ldg16(base + (size_t)p * C), v);
+        unpackr<T>(ldraw<T>(base + (size_t)p * C), v);
         float a = 0.f, b = 0.f;
 #pragma unroll
         for (int j = 0; j < N; ++j) { a += v[j]; b += v[j] * v[j]; }
@@ -225,11 +231,13 @@ extern "C" int mnet_groupnorm_affine(const void* x, int32_t dtype, int32_t n, in
                                      double* partial, int32_t slices, float* scale, float* shift, void* stream) {
     MNET_CHECK_ARG(x && gamma && beta && partial && scale && shift, "groupnorm: null pointer");
     MNET_CHECK_ARG(n > 0 && h > 0 && w > 0 && c > 0 && slices > 0 && n <= 65535, "groupnorm: bad geometry");
-    MNET_CHECK_ARG(dtype == MNET_F32 || dtype == MNET_F16, "groupnorm: bad dtype");
-    const int N = dtype == MNET_F16 ? 8 : 4;
+    MNET_CHECK_ARG(dtype == MNET_F32 || dtype == MNET_F16 || dtype == MNET_F16X2, "groupnorm: bad dtype");
+    const int N = dtype == MNET_F32 ? 4 : 8;
     MNET_CHECK_ALIGN(c % 32 == 0 && 256 % (c / N) == 0 && aligned16(x), "groupnorm: c=%d unsupported", c);
+    MNET_CHECK_ALIGN(dtype != MNET_F16X2 || aligned128(x), "groupnorm: split-half tensors must be 128-byte aligned");
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     if (dtype == MNET_F16) hipLaunchKernelGGL(gn_partial_kernel<f16>, dim3(slices, n), dim3(256), 0, st, (const f16*)x, h, w, c, valid_w, partial, slices);
+    else if (dtype == MNET_F16X2) hipLaunchKernelGGL(gn_partial_kernel<hs>, dim3(slices, n), dim3(256), 0, st, (const hs*)x, h, w, c, valid_w, partial, slices);
     else hipLaunchKernelGGL(gn_partial_kernel<float>, dim3(slices, n), dim3(256), 0, st, (const float*)x, h, w, c, valid_w, partial, slices);
     MNET_LAUNCH_CHECK("gn_partial");
     const int tot = n * c;
@@ -268,8 +276,8 @@ __global__ void __launch_bounds__(256) adain_crop_kernel(const T* __restrict__ p
     for (int p = pl; p < npx; p += plane) {
         const int y = p / gw, x = p - y * gw;
         float a[N], b[N];
-        Vec<T>::unpack(ldg16(pbase + ((size_t)y * S + (y1 + x)) * C), a);
-        Vec<T>::unpack(ldg16(fbase + ((size_t)y * FW + (x1 + x)) * C), b);
+        unpackr<T>(ldraw<T>(pbase + ((size_t)y * S + (y1 + x)) * C), a);
+        unpackr<T>(ldraw<T>(fbase + ((size_t)y * FW + (x1 + x)) * C), b);
 #pragma unroll
         for (int j = 0; j < N; ++j) {
             ps_[j] += (double)a[j]; pss[j] += (double)a[j] * (double)a[j];
@@ -330,20 +338,20 @@ __global__ void __launch_bounds__(256) adain_crop_kernel(const T* __restrict__ p
     const int c0 = ch * N;
     for (int p = pl; p < S * S; p += plane) {
         const int y = p / S, x = p - y * S;
-        u32x4 oa = {0u, 0u, 0u, 0u}, ob = {0u, 0u, 0u, 0u};
+        Raw<T> oa = zero_raw<T>(), ob = zero_raw<T>();
         if (x < gw) {
             float a[N], o[N];
-            Vec<T>::unpack(ldg16(pbase + ((size_t)y * S + (y1 + x)) * C), a);
-            ob = ldg16(fbase + ((size_t)y * FW + (x1 + x)) * C);
+            unpackr<T>(ldraw<T>(pbase + ((size_t)y * S + (y1 + x)) * C), a);
+            ob = ldraw<T>(fbase + ((size_t)y * FW + (x1 + x)) * C);
 #pragma unroll
             for (int j = 0; j < N; ++j) {
                 const int c = c0 + j;
                 o[j] = (a[j] - stat[c]) / stat[C + c] * stat[3 * C + c] + stat[2 * C + c];
             }
-            oa = Vec<T>::pack(o);
+            oa = packr<T>(o);
         }
-        stg16(obase + (size_t)p * 2 * C + c0, oa);
-        stg16(obase + (size_t)p * 2 * C + C + c0, ob);
+        straw<T>(obase + (size_t)p * 2 * C + c0, oa);
+        straw<T>(obase + (size_t)p * 2 * C + C + c0, ob);
     }
 }
 
@@ -352,16 +360,21 @@ static int adain_launch(const void* prior, const void* feat, void* out, int32_t 
                         const float* gamma, const float* beta, float eps, float* scale, float* shift, void* stream) {
     MNET_CHECK_ARG(prior && feat && out && g_img && g_x1 && g_y1 && g_w, "adain: null pointer");
     MNET_CHECK_ARG(G > 0 && S > 0 && C > 0 && feat_w >= S, "adain: bad geometry");
-    MNET_CHECK_ARG(dtype == MNET_F32 || dtype == MNET_F16, "adain: bad dtype");
-    const int N = dtype == MNET_F16 ? 8 : 4;
+    MNET_CHECK_ARG(dtype == MNET_F32 || dtype == MNET_F16 || dtype == MNET_F16X2, "adain: bad dtype");
+    const int N = dtype == MNET_F32 ? 4 : 8;
     MNET_CHECK_ALIGN(C % N == 0 && 256 % (C / N) == 0 && C % 32 == 0 && aligned16(prior) && aligned16(feat) && aligned16(out),
                      "adain: C=%d unsupported or unaligned", C);
+    MNET_CHECK_ALIGN(dtype != MNET_F16X2 || (aligned128(prior) && aligned128(feat) && aligned128(out)), "adain: split-half tensors must be 128-byte aligned");
     const size_t lds = (size_t)256 * N * 4 * sizeof(double) + (size_t)4 * C * sizeof(float) + (size_t)4 * C * sizeof(double) +
                        (size_t)(2 * C / 32) * 2 * sizeof(float);
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-    static thread_local size_t lds_all[256][2] = {};                   // attribute raised once per (device, size) (not during graph capture replays)
+    static thread_local size_t lds_all[256][3] = {};                   // attribute raised once per (device, size) (not during graph capture replays)
     size_t* lds_set = lds_all[DeviceOnce::dev()];
-    if (dtype == MNET_F16) {
+    if (dtype == MNET_F16X2) {
+        if (lds > lds_set[2]) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(adain_crop_kernel<hs>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); lds_set[2] = lds; }
+        hipLaunchKernelGGL(adain_crop_kernel<hs>, dim3(G), dim3(256), lds, st, (const hs*)prior, (const hs*)feat, (hs*)out, S, C, feat_w,
+                           g_img, g_x1, g_y1, g_w, gamma, beta, eps, scale, shift);
+    } else if (dtype == MNET_F16) {
         if (lds > lds_set[1]) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(adain_crop_kernel<f16>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); lds_set[1] = lds; }
         hipLaunchKernelGGL(adain_crop_kernel<f16>, dim3(G), dim3(256), lds, st, (const f16*)prior, (const f16*)feat, (f16*)out, S, C, feat_w,
                            g_img, g_x1, g_y1, g_w, gamma, beta, eps, scale, shift);
@@ -417,8 +430,8 @@ __global__ void __launch_bounds__(256) adain_stats_kernel(const T* __restrict__ 
     for (int p = sl * per + pl; p < p_end; p += plane) {
         const int y = p / gw, x = p - y * gw;
         float a[N], b[N];
-        Vec<T>::unpack(ldg16(pbase + ((size_t)y * S + (y1 + x)) * C), a);
-        Vec<T>::unpack(ldg16(fbase + ((size_t)y * FW + (x1 + x)) * C), b);
+        unpackr<T>(ldraw<T>(pbase + ((size_t)y * S + (y1 + x)) * C), a);
+        unpackr<T>(ldraw<T>(fbase + ((size_t)y * FW + (x1 + x)) * C), b);
 #pragma unroll
         for (int j = 0; j < N; ++j) {
             ps_[j] += (double)a[j]; pss[j] += (double)a[j] * (double)a[j];
@@ -515,20 +528,20 @@ __global__ void __launch_bounds__(256) adain_apply_kernel(const T* __restrict__ 
     const int per = (S * S + slices - 1) / slices, p_end = min(S * S, (sl + 1) * per);
     for (int p = sl * per + pl; p < p_end; p += plane) {
         const int y = p / S, x = p - y * S;
-        u32x4 oa = {0u, 0u, 0u, 0u}, ob = {0u, 0u, 0u, 0u};
+        Raw<T> oa = zero_raw<T>(), ob = zero_raw<T>();
         if (x < gw) {
             float a[N], o[N];
-            Vec<T>::unpack(ldg16(pbase + ((size_t)y * S + (y1 + x)) * C), a);
-            ob = ldg16(fbase + ((size_t)y * FW + (x1 + x)) * C);
+            unpackr<T>(ldraw<T>(pbase + ((size_t)y * S + (y1 + x)) * C), a);
+            ob = ldraw<T>(fbase + ((size_t)y * FW + (x1 + x)) * C);
 #pragma unroll
             for (int j = 0; j < N; ++j) {
                 const int c = c0 + j;
                 o[j] = (a[j] - stat[c]) / stat[C + c] * stat[3 * C + c] + stat[2 * C + c];
             }
-            oa = Vec<T>::pack(o);
+            oa = packr<T>(o);
         }
-        stg16(obase + (size_t)p * 2 * C + c0, oa);
-        stg16(obase + (size_t)p * 2 * C + C + c0, ob);
+        straw<T>(obase + (size_t)p * 2 * C + c0, oa);
+        straw<T>(obase + (size_t)p * 2 * C + C + c0, ob);
     }
 }
 
@@ -539,10 +552,11 @@ extern "C" int mnet_adain_crop_concat_split(const void* prior, const void* feat,
                                             double* partial, float* stat, int32_t slices, void* stream) {
     MNET_CHECK_ARG(prior && feat && out && g_img && g_x1 && g_y1 && g_w && partial && stat, "adain_split: null pointer");
     MNET_CHECK_ARG(G > 0 && G <= 65535 && S > 0 && C > 0 && feat_w >= S && slices > 0 && slices <= 1024, "adain_split: bad geometry");
-    MNET_CHECK_ARG(dtype == MNET_F32 || dtype == MNET_F16, "adain_split: bad dtype");
+    MNET_CHECK_ARG(dtype == MNET_F32 || dtype == MNET_F16 || dtype == MNET_F16X2, "adain_split: bad dtype");
+    MNET_CHECK_ALIGN(dtype != MNET_F16X2 || (aligned128(prior) && aligned128(feat) && aligned128(out)), "adain_split: split-half tensors must be 128-byte aligned");
     MNET_CHECK_ARG((gamma != nullptr) == (beta != nullptr) && (gamma != nullptr) == (scale != nullptr) && (gamma != nullptr) == (shift != nullptr),
                    "adain_split: gamma, beta, scale, shift go together");
-    const int N = dtype == MNET_F16 ? 8 : 4;
+    const int N = dtype == MNET_F32 ? 4 : 8;
     MNET_CHECK_ALIGN(C % N == 0 && 256 % (C / N) == 0 && C % 32 == 0 && aligned16(prior) && aligned16(feat) && aligned16(out),
                      "adain_split: C=%d unsupported or unaligned", C);
     const size_t lds1 = (size_t)256 * N * 4 * sizeof(double);
@@ -553,14 +567,17 @@ extern "C" int mnet_adain_crop_concat_split(const void* prior, const void* feat,
     static thread_local DeviceOnce attr_once;
     if (!attr_once.done()) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(adain_stats_kernel<f16>), hipFuncAttributeMaxDynamicSharedMemorySize, 256 * 8 * 4 * 8);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(adain_stats_kernel<hs>), hipFuncAttributeMaxDynamicSharedMemorySize, 256 * 8 * 4 * 8);
         attr_once.mark();
     }
     if (dtype == MNET_F16) hipLaunchKernelGGL(adain_stats_kernel<f16>, dim3(slices, G), dim3(256), lds1, st, (const f16*)prior, (const f16*)feat, S, C, feat_w, g_img, g_x1, g_y1, g_w, partial, slices);
+    else if (dtype == MNET_F16X2) hipLaunchKernelGGL(adain_stats_kernel<hs>, dim3(slices, G), dim3(256), lds1, st, (const hs*)prior, (const hs*)feat, S, C, feat_w, g_img, g_x1, g_y1, g_w, partial, slices);
     else hipLaunchKernelGGL(adain_stats_kernel<float>, dim3(slices, G), dim3(256), lds1, st, (const float*)prior, (const float*)feat, S, C, feat_w, g_img, g_x1, g_y1, g_w, partial, slices);
     MNET_LAUNCH_CHECK("adain_stats");
     hipLaunchKernelGGL(adain_finalize_kernel, dim3(G), dim3(256), lds2, st, partial, slices, S, C, g_w, stat, gamma, beta, eps, scale, shift);
     MNET_LAUNCH_CHECK("adain_finalize");
     if (dtype == MNET_F16) hipLaunchKernelGGL(adain_apply_kernel<f16>, dim3(slices, G), dim3(256), lds3, st, (const f16*)prior, (const f16*)feat, (f16*)out, S, C, feat_w, g_img, g_x1, g_y1, g_w, stat, slices);
+    else if (dtype == MNET_F16X2) hipLaunchKernelGGL(adain_apply_kernel<hs>, dim3(slices, G), dim3(256), lds3, st, (const hs*)prior, (const hs*)feat, (hs*)out, S, C, feat_w, g_img, g_x1, g_y1, g_w, stat, slices);
     else hipLaunchKernelGGL(adain_apply_kernel<float>, dim3(slices, G), dim3(256), lds3, st, (const float*)prior, (const float*)feat, (float*)out, S, C, feat_w, g_img, g_x1, g_y1, g_w, stat, slices);
     MNET_LAUNCH_CHECK("adain_apply");
     return MNET_OK;
@@ -590,22 +607,22 @@ __global__ void __launch_bounds__(256) glyph_scatter_kernel(const T* __restrict_
     T* op = out + (size_t)b * S * row + (size_t)id * N;
     if (owner < 0) {
 #pragma unroll 4
-        for (int y = 0; y < S; ++y) stg16(op + (size_t)y * row, ldg16(fp + (size_t)y * row));
+        for (int y = 0; y < S; ++y) straw<T>(op + (size_t)y * row, ldraw<T>(fp + (size_t)y * row));
         return;
     }
     const size_t go = ((size_t)owner * S * S + ox) * C + (size_t)ch * N;     // + y*S*C per row
 #pragma unroll 4
     for (int y = 0; y < S; ++y) {
         float f[N], sc[N], sh[N], o[N];
-        Vec<T>::unpack(ldg16(fp + (size_t)y * row), f);
-        Vec<T>::unpack(ldg16(scale + go + (size_t)y * S * C), sc);
-        Vec<T>::unpack(ldg16(shift + go + (size_t)y * S * C), sh);
+        unpackr<T>(ldraw<T>(fp + (size_t)y * row), f);
+        unpackr<T>(ldraw<T>(scale + go + (size_t)y * S * C), sc);
+        unpackr<T>(ldraw<T>(shift + go + (size_t)y * S * C), sh);
 #pragma unroll
         for (int j = 0; j < N; ++j) {
             const float r = __fadd_rn(__fmul_rn(f[j], sc[j]), sh[j]);    // res = f*scale + shift  (:448)
             o[j] = __fadd_rn(f[j], r);                                    // ori + res             (:449)
         }
-        stg16(op + (size_t)y * row, Vec<T>::pack(o));
+        straw<T>(op + (size_t)y * row, packr<T>(o));
     }
 }
 
@@ -614,14 +631,17 @@ extern "C" int mnet_glyph_scatter_affine(const void* feat, const void* scale, co
                                          const int32_t* g_start, const int32_t* g_x1, const int32_t* g_w, void* stream) {
     MNET_CHECK_ARG(feat && scale && shift && out && g_start && g_x1 && g_w, "scatter: null pointer");
     MNET_CHECK_ARG(B > 0 && S > 0 && C > 0 && feat_w > 0, "scatter: bad geometry");
-    MNET_CHECK_ARG(dtype == MNET_F32 || dtype == MNET_F16, "scatter: bad dtype");
-    const int N = dtype == MNET_F16 ? 8 : 4;
+    MNET_CHECK_ARG(dtype == MNET_F32 || dtype == MNET_F16 || dtype == MNET_F16X2, "scatter: bad dtype");
+    const int N = dtype == MNET_F32 ? 4 : 8;
+    MNET_CHECK_ALIGN(dtype != MNET_F16X2 || (C % 32 == 0 && aligned128(feat) && aligned128(scale) && aligned128(shift) && aligned128(out)),
+                     "scatter: split-half needs C %% 32 == 0, 128-byte aligned");
     MNET_CHECK_ALIGN(C % N == 0 && aligned16(feat) && aligned16(scale) && aligned16(shift) && aligned16(out),
                      "scatter: unaligned");
     MNET_CHECK_ARG(B <= 65535, "scatter: too many images");
     const int blocks = (int)(((long long)feat_w * (C / N) + 255) / 256);
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     if (dtype == MNET_F16) hipLaunchKernelGGL(glyph_scatter_kernel<f16>, dim3(blocks, B), dim3(256), 0, st, (const f16*)feat, (const f16*)scale, (const f16*)shift, (f16*)out, S, C, feat_w, g_start, g_x1, g_w);
+    else if (dtype == MNET_F16X2) hipLaunchKernelGGL(glyph_scatter_kernel<hs>, dim3(blocks, B), dim3(256), 0, st, (const hs*)feat, (const hs*)scale, (const hs*)shift, (hs*)out, S, C, feat_w, g_start, g_x1, g_w);
     else hipLaunchKernelGGL(glyph_scatter_kernel<float>, dim3(blocks, B), dim3(256), 0, st, (const float*)feat, (const float*)scale, (const float*)shift, (float*)out, S, C, feat_w, g_start, g_x1, g_w);
     MNET_LAUNCH_CHECK("glyph_scatter");
     return MNET_OK;
@@ -644,20 +664,22 @@ __global__ void __launch_bounds__(256) embed_gather_kernel(const float* __restri
         float v[N];
 #pragma unroll
         for (int j = 0; j < N; ++j) v[j] = e[j];
-        stg16(out + (size_t)id * N, Vec<T>::pack(v));
+        straw<T>(out + (size_t)id * N, packr<T>(v));
     }
 }
 
 extern "C" int mnet_embed_gather(const float* emb, const int64_t* labels, void* out, int32_t dtype, int32_t N_,
                                  int32_t nc, int32_t C, int32_t num_classes, void* stream) {
     MNET_CHECK_ARG(emb && labels && out && N_ > 0 && nc > 0 && C > 0 && num_classes > 0, "embed_gather: bad args");
-    MNET_CHECK_ARG(dtype == MNET_F32 || dtype == MNET_F16, "embed_gather: bad dtype");
-    const int N = dtype == MNET_F16 ? 8 : 4;
+    MNET_CHECK_ARG(dtype == MNET_F32 || dtype == MNET_F16 || dtype == MNET_F16X2, "embed_gather: bad dtype");
+    const int N = dtype == MNET_F32 ? 4 : 8;
     MNET_CHECK_ALIGN(C % N == 0 && aligned16(out), "embed_gather: unaligned");
+    MNET_CHECK_ALIGN(dtype != MNET_F16X2 || (C % 32 == 0 && aligned128(out)), "embed_gather: split-half needs C %% 32 == 0, 128-byte aligned");
     const long long total = (long long)N_ * 16 * nc * (C / N);
     const int blocks = (int)((total + 255) / 256 < 16384 ? (total + 255) / 256 : 16384);
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     if (dtype == MNET_F16) hipLaunchKernelGGL(embed_gather_kernel<f16>, dim3(blocks), dim3(256), 0, st, emb, labels, (f16*)out, nc, C, total);
+    else if (dtype == MNET_F16X2) hipLaunchKernelGGL(embed_gather_kernel<hs>, dim3(blocks), dim3(256), 0, st, emb, labels, (hs*)out, nc, C, total);
     else hipLaunchKernelGGL(embed_gather_kernel<float>, dim3(blocks), dim3(256), 0, st, emb, labels, (float*)out, nc, C, total);
     MNET_LAUNCH_CHECK("embed_gather");
     return MNET_OK;
@@ -722,26 +744,42 @@ extern "C" int mnet_demod(const float* style, const float* wsq_t, float* demod, 
 }
 
 // ============================================================================ dtype conversion (flat)
+// 8 logical elements per thread-iteration (one chunk of f16 / split-half, two chunks of f32).  Split-half tensors are
+// channel-minor with C % 32 == 0, so their 32-element blocks tile the flat index space too.
+template <typename T> __device__ __forceinline__ void ld8(const T* p, float* v) { unpackr<T>(ldraw<T>(p), v); }
+template <> __device__ __forceinline__ void ld8<float>(const float* p, float* v) { Vec<float>::unpack(ldg16(p), v); Vec<float>::unpack(ldg16(p + 4), v + 4); }
+template <typename T> __device__ __forceinline__ void st8(T* p, const float* v) { straw<T>(p, packr<T>(v)); }
+template <> __device__ __forceinline__ void st8<float>(float* p, const float* v) { stg16(p, Vec<float>::pack(v)); stg16(p + 4, Vec<float>::pack(v + 4)); }
+
 template <typename S, typename D>
-__global__ void __launch_bounds__(256) convert_kernel(const S* __restrict__ src, D* __restrict__ dst, long long n4) {
-    // 4 elements per thread-iteration
-    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long long)gridDim.x * blockDim.x) {
-        const S* s = src + i * 4; D* d = dst + i * 4;
-        const float a = (float)s[0], b = (float)s[1], c = (float)s[2], e = (float)s[3];
-        d[0] = (D)a; d[1] = (D)b; d[2] = (D)c; d[3] = (D)e;
+__global__ void __launch_bounds__(256) convert_kernel(const S* __restrict__ src, D* __restrict__ dst, long long n8) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += (long long)gridDim.x * blockDim.x) {
+        float v[8];
+        ld8<S>(src + i * 8, v);
+        st8<D>(dst + i * 8, v);
     }
 }
 
+template <typename S>
+static void convert_from(const void* src, void* dst, int32_t dst_dtype, long long n8, int blocks, hipStream_t st) {
+    if (dst_dtype == MNET_F32) hipLaunchKernelGGL((convert_kernel<S, float>), dim3(blocks), dim3(256), 0, st, (const S*)src, (float*)dst, n8);
+    else if (dst_dtype == MNET_F16) hipLaunchKernelGGL((convert_kernel<S, f16>), dim3(blocks), dim3(256), 0, st, (const S*)src, (f16*)dst, n8);
+    else hipLaunchKernelGGL((convert_kernel<S, hs>), dim3(blocks), dim3(256), 0, st, (const S*)src, (hs*)dst, n8);
+}
+
 extern "C" int mnet_convert(const void* src, int32_t src_dtype, void* dst, int32_t dst_dtype, int64_t count, void* stream) {
-    MNET_CHECK_ARG(src && dst && count > 0 && count % 4 == 0, "convert: bad args (count %% 4 == 0)");
-    MNET_CHECK_ARG((src_dtype == MNET_F32 || src_dtype == MNET_F16) && (dst_dtype == MNET_F32 || dst_dtype == MNET_F16), "convert: bad dtype");
-    const long long n4 = count / 4;
-    const int blocks = (int)((n4 + 255) / 256 < 16384 ? (n4 + 255) / 256 : 16384);
+    MNET_CHECK_ARG(src && dst && count > 0 && count % 8 == 0, "convert: bad args (count %% 8 == 0)");
+    MNET_CHECK_ARG(src_dtype >= MNET_F32 && src_dtype <= MNET_F16X2 && dst_dtype >= MNET_F32 && dst_dtype <= MNET_F16X2, "convert: bad dtype");
+    MNET_CHECK_ALIGN(aligned16(src) && aligned16(dst), "convert: unaligned pointer");
+    MNET_CHECK_ALIGN((src_dtype != MNET_F16X2 || aligned128(src)) && (dst_dtype != MNET_F16X2 || aligned128(dst)) &&
+                     ((src_dtype != MNET_F16X2 && dst_dtype != MNET_F16X2) || count % 32 == 0),
+                     "convert: split-half tensors need count %% 32 == 0 and a 128-byte aligned base");
+    const long long n8 = count / 8;
+    const int blocks = (int)((n8 + 255) / 256 < 16384 ? (n8 + 255) / 256 : 16384);
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-    if (src_dtype == MNET_F16 && dst_dtype == MNET_F32) hipLaunchKernelGGL((convert_kernel<f16, float>), dim3(blocks), dim3(256), 0, st, (const f16*)src, (float*)dst, n4);
-    else if (src_dtype == MNET_F32 && dst_dtype == MNET_F16) hipLaunchKernelGGL((convert_kernel<float, f16>), dim3(blocks), dim3(256), 0, st, (const float*)src, (f16*)dst, n4);
-    else if (src_dtype == MNET_F32) hipLaunchKernelGGL((convert_kernel<float, float>), dim3(blocks), dim3(256), 0, st, (const float*)src, (float*)dst, n4);
-    else hipLaunchKernelGGL((convert_kernel<f16, f16>), dim3(blocks), dim3(256), 0, st, (const f16*)src, (f16*)dst, n4);
+    if (src_dtype == MNET_F32) convert_from<float>(src, dst, dst_dtype, n8, blocks, st);
+    else if (src_dtype == MNET_F16) convert_from<f16>(src, dst, dst_dtype, n8, blocks, st);
+    else convert_from<hs>(src, dst, dst_dtype, n8, blocks, st);
     MNET_LAUNCH_CHECK("convert");
     return MNET_OK;
 }
@@ -798,22 +836,23 @@ __global__ void __launch_bounds__(256) affine_act_kernel(const T* __restrict__ x
     T* yb = y + (size_t)n * chunks_per_image * N;
     for (unsigned id = first; id < chunks_per_image; id += gridDim.x * 256u) {      // stride % cpp == 0 (host)
         float v[N];
-        Vec<T>::unpack(ldg16(xb + (size_t)id * N), v);
+        unpackr<T>(ldraw<T>(xb + (size_t)id * N), v);
 #pragma unroll
         for (int j = 0; j < N; ++j) {
             float t = v[j] * sc[j] + sh[j];
             if (swish) t = t * __builtin_amdgcn_rcpf(1.f + __expf(-t));       // v_exp_f32 / v_rcp_f32: ~1 ulp each
             v[j] = t;
         }
-        stg16(yb + (size_t)id * N, Vec<T>::pack(v));
+        straw<T>(yb + (size_t)id * N, packr<T>(v));
     }
 }
 
 extern "C" int mnet_affine_act_nhwc(const void* x, void* y, int32_t dtype, int32_t n, int32_t hw, int32_t c,
                                     const float* scale, const float* shift, int32_t swish, void* stream) {
     MNET_CHECK_ARG(x && y && scale && n > 0 && hw > 0 && c > 0 && n <= 65535, "affine_act: bad args");
-    MNET_CHECK_ARG(dtype == MNET_F32 || dtype == MNET_F16, "affine_act: bad dtype");
-    const int N = dtype == MNET_F16 ? 8 : 4;
+    MNET_CHECK_ARG(dtype == MNET_F32 || dtype == MNET_F16 || dtype == MNET_F16X2, "affine_act: bad dtype");
+    const int N = dtype == MNET_F32 ? 4 : 8;
+    MNET_CHECK_ALIGN(dtype != MNET_F16X2 || (c % 32 == 0 && aligned128(x) && aligned128(y)), "affine_act: split-half needs c %% 32 == 0, 128-byte aligned");
     MNET_CHECK_ALIGN(c % N == 0 && 256 % (c / N) == 0 && aligned16(x) && aligned16(y) && aligned16(scale) && aligned16(shift),
                      "affine_act: c=%d unsupported or unaligned", c);
     const long long per = (long long)hw * (c / N);
@@ -821,6 +860,7 @@ extern "C" int mnet_affine_act_nhwc(const void* x, void* y, int32_t dtype, int32
     const int gx = (int)((per + 255) / 256 < 1024 ? (per + 255) / 256 : 1024);
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     if (dtype == MNET_F16) hipLaunchKernelGGL(affine_act_kernel<f16>, dim3(gx, n), dim3(256), 0, st, (const f16*)x, (f16*)y, c, scale, shift, swish, (unsigned)per);
+    else if (dtype == MNET_F16X2) hipLaunchKernelGGL(affine_act_kernel<hs>, dim3(gx, n), dim3(256), 0, st, (const hs*)x, (hs*)y, c, scale, shift, swish, (unsigned)per);
     else hipLaunchKernelGGL(affine_act_kernel<float>, dim3(gx, n), dim3(256), 0, st, (const float*)x, (float*)y, c, scale, shift, swish, (unsigned)per);
     MNET_LAUNCH_CHECK("affine_act");
     return MNET_OK;
@@ -872,7 +912,9 @@ template <typename T> struct RgbW;            // weight element as the kernel re
 template <> struct RgbW<f16> { typedef unsigned int pair_t; };   // two f16 packed
 template <> struct RgbW<float> { typedef float pair_t; };
 
-template <typename T, int CIN>
+// SPLIT (T = float): the input is a split-half tensor, converted to fp32 while it is staged; weights, arithmetic and both
+// outputs are the fp32 ones.
+template <typename T, int CIN, bool SPLIT = false>
 __global__ void __launch_bounds__(256) conv3x3_rgb_kernel(const T* __restrict__ x, const void* __restrict__ wgt_,
                                                           const float* __restrict__ bias, T* __restrict__ y_nhwc,
                                                           float* __restrict__ y_nchw, int H, int W, int act) {
@@ -890,6 +932,18 @@ __global__ void __launch_bounds__(256) conv3x3_rgb_kernel(const T* __restrict__ 
     const int y0 = ty * TH - 1, x0 = tx * TW - 1;              // patch origin (halo included)
     const T* xb = x + (size_t)n * H * W * CIN;
     // stage the patch (zero halo outside the image)
+    if constexpr (SPLIT) {
+        const hs* xs = reinterpret_cast<const hs*>(x) + (size_t)n * H * W * CIN;
+        for (int i = t; i < PH * PW * (CIN / 8); i += 256) {
+            const int c8 = i % (CIN / 8), q = i / (CIN / 8);
+            const int py = q / PW, px = q - py * PW;
+            const int gy = y0 + py, gx = x0 + px;
+            float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+            if ((unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W) unpackr<hs>(ldraw<hs>(xs + ((size_t)gy * W + gx) * CIN + c8 * 8), v);
+            *reinterpret_cast<u32x4*>(dyn + lds_off(q, 2 * c8)) = Vec<float>::pack(v);
+            *reinterpret_cast<u32x4*>(dyn + lds_off(q, 2 * c8 + 1)) = Vec<float>::pack(v + 4);
+        }
+    } else
     for (int i = t; i < PH * PW * CH; i += 256) {
         const int c = i % CH, q = i / CH;
         const int py = q / PW, px = q - py * PW;
@@ -957,8 +1011,9 @@ __global__ void __launch_bounds__(256) conv3x3_rgb_kernel(const T* __restrict__ 
 extern "C" int mnet_conv3x3_rgb(const void* x, int32_t dtype, int32_t n, int32_t h, int32_t w, int32_t cin, const void* wgt,
                                 const float* bias, int32_t act, void* y_nhwc, float* y_nchw, void* stream) {
     MNET_CHECK_ARG(x && wgt && bias && (y_nhwc || y_nchw) && n > 0 && h > 0 && w > 0 && n <= 65535, "conv3x3_rgb: bad args");
-    MNET_CHECK_ARG(dtype == MNET_F32 || dtype == MNET_F16, "conv3x3_rgb: bad dtype");
+    MNET_CHECK_ARG(dtype == MNET_F32 || dtype == MNET_F16 || dtype == MNET_F16X2, "conv3x3_rgb: bad dtype");
     MNET_CHECK_ARG(cin == 64, "conv3x3_rgb: cin=%d (supported: 64)", cin);
+    MNET_CHECK_ALIGN(dtype != MNET_F16X2 || aligned128(x), "conv3x3_rgb: split-half input must be 128-byte aligned");
     MNET_CHECK_ARG(act == MNET_ACT_NONE || act == MNET_ACT_TANH, "conv3x3_rgb: act %d", act);
     MNET_CHECK_ALIGN(aligned16(x) && aligned16(y_nhwc) && aligned16(wgt), "conv3x3_rgb: unaligned pointer");
     const int tiles = ((h + 7) / 8) * ((w + 31) / 32);
@@ -971,10 +1026,12 @@ extern "C" int mnet_conv3x3_rgb(const void* x, int32_t dtype, int32_t n, int32_t
         static thread_local DeviceOnce attr_once;
         if (!attr_once.done()) {
             hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_rgb_kernel<float, 64>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+            if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_rgb_kernel<float, 64, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
             if (e != hipSuccess) return mnet_fail(MNET_E_LAUNCH, "hipFuncSetAttribute(conv3x3_rgb): %s", hipGetErrorString(e));
             attr_once.mark();
         }
-        hipLaunchKernelGGL((conv3x3_rgb_kernel<float, 64>), dim3(tiles, n), dim3(256), lds, st, (const float*)x, wgt, bias, (float*)y_nhwc, y_nchw, h, w, act);
+        if (dtype == MNET_F16X2) hipLaunchKernelGGL((conv3x3_rgb_kernel<float, 64, true>), dim3(tiles, n), dim3(256), lds, st, (const float*)x, wgt, bias, (float*)y_nhwc, y_nchw, h, w, act);
+        else hipLaunchKernelGGL((conv3x3_rgb_kernel<float, 64>), dim3(tiles, n), dim3(256), lds, st, (const float*)x, wgt, bias, (float*)y_nhwc, y_nchw, h, w, act);
     }
     MNET_LAUNCH_CHECK("conv3x3_rgb");
     return MNET_OK;

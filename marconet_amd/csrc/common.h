@@ -66,6 +66,76 @@ template <> struct Vec<f16> {
     }
 };
 
+// ---------------------------------------------------------------------------------------------------------------------
+// MNET_F16X2 — "split half" storage of the fp16x3 precision mode.  A logical element is a PAIR of halves (hi, lo) with
+// value = float(hi) + float(lo), hi = f16(v), lo = f16(v - float(hi)): ~22 significant bits, the range of fp16.
+// Layout of an NHWC tensor [.., C] (C % 32 == 0, base 128-byte aligned): per pixel 4*C bytes, in blocks of 32 channels —
+//     bytes [128 b, 128 b + 64)      hi of channels 32 b .. 32 b + 31
+//     bytes [128 b + 64, 128 b + 128) lo of the same channels
+// so that ONE 128-byte k-slab of the implicit-GEMM kernels is exactly one 32-channel block: 16-byte chunks 0-3 are the MFMA
+// operand of the hi part, chunks 4-7 of the lo part, and x*w is evaluated as hi*hi + hi*lo + lo*hi (three fp16 MFMAs into one
+// fp32 accumulator) from a single LDS image of the slab.  Conv weights of this mode hold hi/lo of 256*W (exponent offset: the
+// lo parts of typical |W| ~ 1e-2 stay normal numbers); the conv epilogue multiplies the accumulator by 2^-8.
+// `hs` is the 4-byte element type tag; pointer arithmetic in units of hs gives NOMINAL addresses (chunk j of a pixel at
+// +32 j bytes) which ldraw / straw map to the real hi / lo locations (chunk j = block j/4, sub-chunk j%4: hi at
+// 128 (j/4) + 16 (j%4), lo 64 bytes further).
+struct hs { unsigned short hi_bits, lo_bits; };
+static_assert(sizeof(hs) == 4, "hs is 4 bytes");
+#define MNET_SPLIT_WSCALE 256.0f
+#define MNET_SPLIT_WSCALE_INV 0.00390625f
+
+template <> struct Vec<hs> { static constexpr int N = 8; };
+
+// raw storage of one chunk of Vec<T>::N consecutive channels
+template <typename T> struct Raw { u32x4 v; };
+template <> struct Raw<hs> { u32x4 hi, lo; };
+
+template <typename T> __device__ __forceinline__ Raw<T> ldraw(const T* p) { Raw<T> r; r.v = ldg16(p); return r; }
+template <> __device__ __forceinline__ Raw<hs> ldraw<hs>(const hs* p) {
+    const uintptr_t a = reinterpret_cast<uintptr_t>(p);
+    const unsigned char* q = reinterpret_cast<const unsigned char*>(a - ((a >> 5) & 3u) * 16u);
+    Raw<hs> r; r.hi = ldg16(q); r.lo = ldg16(q + 64); return r;
+}
+template <typename T> __device__ __forceinline__ void straw(T* p, const Raw<T>& r) { stg16(p, r.v); }
+template <> __device__ __forceinline__ void straw<hs>(hs* p, const Raw<hs>& r) {
+    const uintptr_t a = reinterpret_cast<uintptr_t>(p);
+    unsigned char* q = reinterpret_cast<unsigned char*>(a - ((a >> 5) & 3u) * 16u);
+    stg16(q, r.hi); stg16(q + 64, r.lo);
+}
+template <typename T> __device__ __forceinline__ Raw<T> zero_raw() { Raw<T> r; r.v = u32x4{0u, 0u, 0u, 0u}; return r; }
+template <> __device__ __forceinline__ Raw<hs> zero_raw<hs>() { Raw<hs> r; r.hi = u32x4{0u, 0u, 0u, 0u}; r.lo = r.hi; return r; }
+
+template <typename T> __device__ __forceinline__ void unpackr(const Raw<T>& r, float* o) { Vec<T>::unpack(r.v, o); }
+template <> __device__ __forceinline__ void unpackr<hs>(const Raw<hs>& r, float* o) {
+    const f16x8 h = bitcast<f16x8>(r.hi), l = bitcast<f16x8>(r.lo);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) o[j] = (float)h[j] + (float)l[j];
+}
+// hi = f16(v), lo = f16(v - hi)  (both round-to-nearest-even; v - hi is exact in fp32)
+__device__ __forceinline__ void split8(const float* o, u32x4& hi, u32x4& lo) {
+    f16x8 h, l;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { h[j] = (f16)o[j]; l[j] = (f16)(o[j] - (float)h[j]); }
+    hi = bitcast<u32x4>(h); lo = bitcast<u32x4>(l);
+}
+template <typename T> __device__ __forceinline__ Raw<T> packr(const float* o) { Raw<T> r; r.v = Vec<T>::pack(o); return r; }
+template <> __device__ __forceinline__ Raw<hs> packr<hs>(const float* o) { Raw<hs> r; split8(o, r.hi, r.lo); return r; }
+
+// single element c of the pixel whose first channel is at `px` (layout kernels; not on a hot path)
+template <typename T> __device__ __forceinline__ float ld_elem(const T* px, int c) { return (float)px[c]; }
+template <> __device__ __forceinline__ float ld_elem<hs>(const hs* px, int c) {
+    const f16* q = reinterpret_cast<const f16*>(px) + (c >> 5) * 64 + (c & 31);
+    return (float)q[0] + (float)q[32];
+}
+template <typename T> __device__ __forceinline__ void st_elem(T* px, int c, float v) { px[c] = (T)v; }
+template <> __device__ __forceinline__ void st_elem<hs>(hs* px, int c, float v) {
+    f16* q = reinterpret_cast<f16*>(px) + (c >> 5) * 64 + (c & 31);
+    const f16 h = (f16)v;
+    q[0] = h; q[32] = (f16)(v - (float)h);
+}
+
+static inline bool aligned128(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 127u) == 0; }
+
 __device__ __forceinline__ float act_apply(float v, int act) {
     switch (act) {
         case MNET_ACT_RELU: return fmaxf(v, 0.f);
