@@ -14,8 +14,16 @@ __device__ __forceinline__ int swz_dma(int row, int chunk) { return row * 128 + 
 #define VMCNT(n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
 
 // store 8 consecutive output channels co..co+7 of pixel `pix` (DBG: diagnostic variants, see launch_dma_id)
-template <int DBG>
+template <int DBG, bool X3 = false>
 __device__ __forceinline__ void store8(const ConvArgs& p, const float* v, int pix, int co) {
+    if constexpr (X3) {                 // split-half output: 8 hi halves, and 64 bytes further the 8 lo halves
+        unsigned char* q = reinterpret_cast<unsigned char*>(p.y) + (size_t)pix * p.cout * 4 + (co >> 5) * 128 + (co & 31) * 2;
+        u32x4 hi, lo;
+        split8(v, hi, lo);
+        stg16(q, hi);
+        stg16(q + 64, lo);
+        return;
+    }
     if constexpr (DBG == 5) {           // DIAGNOSTIC: no stores (values kept live)
         asm volatile("" :: "v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]), "v"(v[4]), "v"(v[5]), "v"(v[6]), "v"(v[7]));
         return;
@@ -42,7 +50,7 @@ __device__ __forceinline__ int dma_weight_channel(int row) {
 // Epilogue of one (cout tile co0, pixel tile pix0): identical math to conv_igemm.hip.  Every lane owns NG groups of 8
 // consecutive output channels for each of its NPX pixels; whole-register-set passes, each behind ONE wave-uniform branch
 // (out_scale / bias / residual / activation / post_scale), then 16-byte stores.
-template <int BC, int BP, int WC, int WP, int MF, int DBG, int FC, int FP>
+template <int BC, int BP, int WC, int WP, int MF, int DBG, int FC, int FP, bool X3 = false>
 __device__ __forceinline__ void dma_epilogue(const ConvArgs& p, const f32x4 (&acc)[FC][FP],
                                              const f32x16 (&acc32)[MF == 32 ? FC / 2 : 1][MF == 32 ? FP / 2 : 1],
                                              int co0, int pix0, int wc, int wp, int lane) {
@@ -64,6 +72,7 @@ __device__ __forceinline__ void dma_epilogue(const ConvArgs& p, const f32x4 (&ac
             for (int q = 0; q < 8; ++q) {
                 if constexpr (MF == 16) ev[px][gi][q] = acc[2 * gi + (q >> 2)][px][q & 3];
                 else ev[px][gi][q] = acc32[gi >> 1][px][(gi & 1) * 8 + q];
+                if constexpr (X3) ev[px][gi][q] *= MNET_SPLIT_WSCALE_INV;     // weights hold 256*W: exact power-of-two rescale
             }
     }
     const int last_pix = p.npix - 1;
@@ -100,9 +109,16 @@ __device__ __forceinline__ void dma_epilogue(const ConvArgs& p, const f32x4 (&ac
 #pragma unroll
             for (int gi = 0; gi < NG; ++gi) {
                 if (eco[gi] >= p.cout) continue;
-                const f16x8 r8 = bitcast<f16x8>(ldg16(rs + (size_t)rpix * p.cout + eco[gi]));
+                if constexpr (X3) {
+                    const f16* rq = rs + (size_t)rpix * p.cout * 2 + (eco[gi] >> 5) * 64 + (eco[gi] & 31);
+                    const f16x8 h8 = bitcast<f16x8>(ldg16(rq)), l8 = bitcast<f16x8>(ldg16(rq + 32));
 #pragma unroll
-                for (int q = 0; q < 8; ++q) ev[px][gi][q] += (float)r8[q];
+                    for (int q = 0; q < 8; ++q) ev[px][gi][q] += (float)h8[q] + (float)l8[q];
+                } else {
+                    const f16x8 r8 = bitcast<f16x8>(ldg16(rs + (size_t)rpix * p.cout + eco[gi]));
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) ev[px][gi][q] += (float)r8[q];
+                }
             }
         }
     }
@@ -125,7 +141,7 @@ __device__ __forceinline__ void dma_epilogue(const ConvArgs& p, const f32x4 (&ac
         if (epix[px] >= p.npix) continue;
 #pragma unroll
         for (int gi = 0; gi < NG; ++gi)
-            if (eco[gi] < p.cout) store8<DBG>(p, ev[px][gi], epix[px], eco[gi]);
+            if (eco[gi] < p.cout) store8<DBG, X3>(p, ev[px][gi], epix[px], eco[gi]);
     }
 }
 

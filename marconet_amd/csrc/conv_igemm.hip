@@ -46,6 +46,12 @@ template <> struct Mma<float> {
 
 __device__ __forceinline__ int swz(int row, int chunk) { return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4); }
 
+// "physical" element of a tensor as the k-loop sees it.  A split-half tensor (MNET_F16X2, T = hs) is walked as an f16 tensor
+// with TWICE the channels: its 128-byte k-slab is one 32-channel block — chunks 0-3 the hi halves, chunks 4-7 the lo halves of
+// the same 32 channels — and the host passes c0 / c1 / cin / K in physical (doubled) units.
+template <typename T> struct Phys { typedef T type; };
+template <> struct Phys<hs> { typedef f16 type; };
+
 template <typename T>
 __device__ __forceinline__ u32x4 in_transform(u32x4 raw, const float* sc, const float* sh, bool swish) {
     constexpr int N = Vec<T>::N;
@@ -66,9 +72,36 @@ __device__ __forceinline__ u32x4 in_transform(u32x4 raw, const float* sc, const 
     return Vec<T>::pack(v);
 }
 
+// split-half input transform: this thread staged 16-byte chunk cc of a slab row (`own`) and its partner chunk cc ^ 4 (`other`):
+// the hi and lo halves of the same 8 channels.  value = hi + lo → affine (+ swish) in fp32 → split again → the thread keeps
+// its own half.  sc / sh point at the 8 LOGICAL channels of the chunk.
+__device__ __forceinline__ u32x4 in_transform_split(u32x4 own, u32x4 other, bool own_is_lo, const float* sc, const float* sh, bool swish) {
+    Raw<hs> r;
+    r.hi = own_is_lo ? other : own;
+    r.lo = own_is_lo ? own : other;
+    float v[8];
+    unpackr<hs>(r, v);
+#pragma unroll
+    for (int j = 0; j < 8; j += 4) {
+        const f32x4 s4 = *reinterpret_cast<const f32x4*>(sc + j);
+        f32x4 b4 = {0.f, 0.f, 0.f, 0.f};
+        if (sh) b4 = *reinterpret_cast<const f32x4*>(sh + j);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) v[j + q] = v[j + q] * s4[q] + b4[q];
+    }
+    if (swish) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = v[j] * (1.f / (1.f + expf(-v[j])));
+    }
+    const Raw<hs> o = packr<hs>(v);
+    return own_is_lo ? o.lo : o.hi;
+}
+
 template <typename T, int BC, int BP, int WC, int WP>
 __global__ void __launch_bounds__(256, 2) conv_igemm_kernel(const ConvArgs p) {
-    constexpr int KCH = 16 / (int)sizeof(T);      // elements per 16-byte chunk
+    typedef typename Phys<T>::type PT;            // element type the k-loop addresses (f16 for split-half)
+    constexpr bool SPLIT = sizeof(T) != sizeof(PT);
+    constexpr int KCH = 16 / (int)sizeof(PT);     // elements per 16-byte chunk
     constexpr int BK = 8 * KCH;                   // elements per 128-byte k-slab
     constexpr int FC = BC / WC / 16, FP = BP / WP / 16;
     constexpr int WROWS = (BC + 31) / 32;         // staged chunks per thread, weight tile
@@ -105,6 +138,7 @@ __global__ void __launch_bounds__(256, 2) conv_igemm_kernel(const ConvArgs p) {
     }
 
     u32x4 wreg[WROWS], xreg[XROWS];
+    u32x4 xreg2[SPLIT ? XROWS : 1];               // split-half + input transform: the partner chunk (other half of the same channels)
     int xc = 0;             // input channel of this thread's chunk in the slab being staged
     unsigned xok = 0;       // per-row validity bits of the slab being staged
     const u32x4 zero4 = {0u, 0u, 0u, 0u};
@@ -122,18 +156,21 @@ __global__ void __launch_bounds__(256, 2) conv_igemm_kernel(const ConvArgs p) {
         for (int i = 0; i < WROWS; ++i) {
             const int row = r0 + 32 * i, co = co0 + row;
             const bool ok = kok && row < BC && co < p.cout;
-            wreg[i] = ok ? ldg16(reinterpret_cast<const T*>(p.wgt) + (size_t)co * p.K + k) : zero4;
+            wreg[i] = ok ? ldg16(reinterpret_cast<const PT*>(p.wgt) + (size_t)co * p.K + k) : zero4;
         }
         // activations (implicit im2col gather; channel concat of two sources)
-        const T* src; int cs, cl;
-        if (c < p.c0) { src = reinterpret_cast<const T*>(p.x0); cs = p.c0; cl = c; }
-        else { src = reinterpret_cast<const T*>(p.x1); cs = p.c1; cl = c - p.c0; }
+        const PT* src; int cs, cl;
+        if (c < p.c0) { src = reinterpret_cast<const PT*>(p.x0); cs = p.c0; cl = c; }
+        else { src = reinterpret_cast<const PT*>(p.x1); cs = p.c1; cl = c - p.c0; }
         xc = c; xok = 0;
 #pragma unroll
         for (int i = 0; i < XROWS; ++i) {
             const int ih = xih[i] + fr, iw = xiw[i] + fs;
             const bool ok = kok && xn[i] >= 0 && (unsigned)ih < (unsigned)p.h && (unsigned)iw < (unsigned)xvw[i];
             xreg[i] = ok ? ldg16(src + ((size_t)(xn[i] * p.h + ih) * p.w + iw) * cs + cl) : zero4;
+            if constexpr (SPLIT) {
+                if (p.in_scale) xreg2[i] = ok ? ldg16(src + ((size_t)(xn[i] * p.h + ih) * p.w + iw) * cs + (cl ^ 32)) : zero4;
+            }
             xok |= (ok ? 1u : 0u) << i;
         }
     };
@@ -151,8 +188,14 @@ __global__ void __launch_bounds__(256, 2) conv_igemm_kernel(const ConvArgs p) {
             const int row = r0 + 32 * i;
             u32x4 v = xreg[i];
             if (p.in_scale && ((xok >> i) & 1u)) {
-                const size_t o = (size_t)xn[i] * p.cin + xc;
-                v = in_transform<T>(v, p.in_scale + o, p.in_shift ? p.in_shift + o : nullptr, p.in_swish != 0);
+                if constexpr (SPLIT) {
+                    // physical channel xc = 64*block + 32*half + 8*sub → logical channel 32*block + 8*sub; [n][cin/2] tables
+                    const size_t o = (size_t)xn[i] * (p.cin >> 1) + ((xc >> 6) << 5) + (xc & 31);
+                    v = in_transform_split(v, xreg2[i], (xc & 32) != 0, p.in_scale + o, p.in_shift ? p.in_shift + o : nullptr, p.in_swish != 0);
+                } else {
+                    const size_t o = (size_t)xn[i] * p.cin + xc;
+                    v = in_transform<T>(v, p.in_scale + o, p.in_shift ? p.in_shift + o : nullptr, p.in_swish != 0);
+                }
             }
             stg16(sx_ + swz(row, cc), v);
         }
@@ -167,6 +210,32 @@ __global__ void __launch_bounds__(256, 2) conv_igemm_kernel(const ConvArgs p) {
     auto compute_slab = [&](int stage) {
         const unsigned char* sw_ = smem + stage * STAGE;
         const unsigned char* sx_ = sw_ + BC * 128;
+        if constexpr (SPLIT) {
+            // one 32-channel block: x*w = hi*hi + hi*lo + lo*hi (the lo*lo term is below fp32 resolution), three
+            // v_mfma_f32_16x16x32_f16 per fragment pair into the same fp32 accumulator
+            u32x4 ah[FC], al[FC], bh[FP], bl[FP];
+#pragma unroll
+            for (int f = 0; f < FC; ++f) {
+                const int row = wc * (BC / WC) + f * 16 + l16;
+                ah[f] = *reinterpret_cast<const u32x4*>(sw_ + swz(row, g));
+                al[f] = *reinterpret_cast<const u32x4*>(sw_ + swz(row, 4 + g));
+            }
+#pragma unroll
+            for (int f = 0; f < FP; ++f) {
+                const int row = wp * (BP / WP) + f * 16 + l16;
+                bh[f] = *reinterpret_cast<const u32x4*>(sx_ + swz(row, g));
+                bl[f] = *reinterpret_cast<const u32x4*>(sx_ + swz(row, 4 + g));
+            }
+#pragma unroll
+            for (int fa = 0; fa < FC; ++fa)
+#pragma unroll
+                for (int fb = 0; fb < FP; ++fb) {
+                    Mma<f16>::run(acc[fa][fb], ah[fa], bh[fb]);
+                    Mma<f16>::run(acc[fa][fb], ah[fa], bl[fb]);
+                    Mma<f16>::run(acc[fa][fb], al[fa], bh[fb]);
+                }
+            return;
+        }
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
             const int chunk = ks * 4 + g;
@@ -184,7 +253,7 @@ __global__ void __launch_bounds__(256, 2) conv_igemm_kernel(const ConvArgs p) {
 #pragma unroll
             for (int fa = 0; fa < FC; ++fa)
 #pragma unroll
-                for (int fb = 0; fb < FP; ++fb) Mma<T>::run(acc[fa][fb], a[fa], b[fb]);
+                for (int fb = 0; fb < FP; ++fb) Mma<PT>::run(acc[fa][fb], a[fa], b[fb]);
         }
     };
 
@@ -204,6 +273,12 @@ __global__ void __launch_bounds__(256, 2) conv_igemm_kernel(const ConvArgs p) {
     // behind ONE wave-uniform branch (a per-element `switch (act)` costs a scalar branch chain per value).
     T* yo = reinterpret_cast<T*>(p.y);
     int epix[FP], eco[FC];
+    if constexpr (SPLIT) {      // weights hold 256*W (exponent offset of the lo halves): exact power-of-two rescale
+#pragma unroll
+        for (int fa = 0; fa < FC; ++fa)
+#pragma unroll
+            for (int fb = 0; fb < FP; ++fb) acc[fa][fb] *= MNET_SPLIT_WSCALE_INV;
+    }
 #pragma unroll
     for (int fb = 0; fb < FP; ++fb) epix[fb] = pix0 + wp * (BP / WP) + fb * 16 + l16;
 #pragma unroll
@@ -237,7 +312,11 @@ __global__ void __launch_bounds__(256, 2) conv_igemm_kernel(const ConvArgs p) {
             for (int fa = 0; fa < FC; ++fa) {
                 if (eco[fa] >= p.cout) continue;
                 const T* rp = rs + (size_t)rpix * p.cout + eco[fa];
-                if constexpr (sizeof(T) == 4) {
+                if constexpr (SPLIT) {
+                    const f16* q = reinterpret_cast<const f16*>(rs + (size_t)rpix * p.cout) + (eco[fa] >> 5) * 64 + (eco[fa] & 31);
+                    const f16x4 h4 = *reinterpret_cast<const f16x4*>(q), l4 = *reinterpret_cast<const f16x4*>(q + 32);
+                    acc[fa][fb] += f32x4{(float)h4[0] + (float)l4[0], (float)h4[1] + (float)l4[1], (float)h4[2] + (float)l4[2], (float)h4[3] + (float)l4[3]};
+                } else if constexpr (sizeof(T) == 4) {
                     acc[fa][fb] += *reinterpret_cast<const f32x4*>(rp);
                 } else {
                     const f16x4 r4 = *reinterpret_cast<const f16x4*>(rp);
@@ -279,7 +358,13 @@ __global__ void __launch_bounds__(256, 2) conv_igemm_kernel(const ConvArgs p) {
             if (eco[fa] >= p.cout) continue;
             T* yp = yo + (size_t)epix[fb] * p.cout + eco[fa];
             const f32x4 v = acc[fa][fb];
-            if constexpr (sizeof(T) == 4) {
+            if constexpr (SPLIT) {
+                f16* q = reinterpret_cast<f16*>(yo + (size_t)epix[fb] * p.cout) + (eco[fa] >> 5) * 64 + (eco[fa] & 31);
+                const f16x4 h4 = {(f16)v[0], (f16)v[1], (f16)v[2], (f16)v[3]};
+                const f16x4 l4 = {(f16)(v[0] - (float)h4[0]), (f16)(v[1] - (float)h4[1]), (f16)(v[2] - (float)h4[2]), (f16)(v[3] - (float)h4[3])};
+                *reinterpret_cast<f16x4*>(q) = h4;
+                *reinterpret_cast<f16x4*>(q + 32) = l4;
+            } else if constexpr (sizeof(T) == 4) {
                 *reinterpret_cast<f32x4*>(yp) = v;
             } else {
                 const f16x4 o4 = {(f16)v[0], (f16)v[1], (f16)v[2], (f16)v[3]};
@@ -339,7 +424,7 @@ static int conv_prepare(const mnet_conv_desc* d, int32_t algo, ConvArgs& a) {
     MNET_CHECK_ARG((algo >= 0 && algo <= 3) || (algo >= MNET_CONV_ALGO_DMA_CFG0 && algo < MNET_CONV_ALGO_DMA_CFG0 + 16) ||
                    (algo >= MNET_CONV_ALGO_STRIP_CFG0 && algo < MNET_CONV_ALGO_STRIP_CFG0 + 3), "conv: bad algo %d", algo);
     MNET_CHECK_ARG(d != nullptr, "conv: null descriptor");
-    MNET_CHECK_ARG(d->dtype == MNET_F32 || d->dtype == MNET_F16, "conv: bad dtype %d", d->dtype);
+    MNET_CHECK_ARG(d->dtype == MNET_F32 || d->dtype == MNET_F16 || d->dtype == MNET_F16X2, "conv: bad dtype %d", d->dtype);
     MNET_CHECK_ARG(d->x0 && d->wgt && d->y, "conv: null tensor pointer");
     MNET_CHECK_ARG(d->n > 0 && d->h > 0 && d->w > 0 && d->ho > 0 && d->wo > 0, "conv: bad geometry");
     MNET_CHECK_ARG(d->c0 > 0 && d->c1 >= 0 && d->cout > 0, "conv: bad channel counts");
@@ -360,17 +445,24 @@ static int conv_prepare(const mnet_conv_desc* d, int32_t algo, ConvArgs& a) {
                      aligned16(d->out_scale) && aligned16(d->bias) && aligned16(d->post_scale), "conv: pointers must be 16-byte aligned");
     const long long npix = (long long)d->n * d->ho * d->wo;
     MNET_CHECK_ARG(npix < (1ll << 31) && (long long)d->n * d->h * d->w < (1ll << 31), "conv: too many pixels");
+    const bool split = d->dtype == MNET_F16X2;
+    if (split) {
+        MNET_CHECK_ALIGN(d->c0 % 32 == 0 && d->c1 % 32 == 0 && d->cout % 32 == 0, "conv: split-half tensors need c0, c1, cout %% 32 == 0 (got %d, %d, %d)", d->c0, d->c1, d->cout);
+        MNET_CHECK_ALIGN(aligned128(d->x0) && aligned128(d->x1) && aligned128(d->wgt) && aligned128(d->y) && aligned128(d->residual),
+                         "conv: split-half tensors must be 128-byte aligned");
+    }
+    const int cm = split ? 2 : 1;        // the k-loop walks a split-half tensor as f16 with twice the channels (hi block | lo block)
 
     a.x0 = d->x0; a.x1 = d->x1; a.wgt = d->wgt; a.y = d->y; a.res = d->residual;
     a.in_scale = d->in_scale; a.in_shift = d->in_shift; a.out_scale = d->out_scale; a.bias = d->bias;
     a.post_scale = d->post_scale;
     a.valid_w = d->valid_w;
-    a.c0 = d->c0; a.c1 = d->c1; a.cin = d->c0 + d->c1;
+    a.c0 = d->c0 * cm; a.c1 = d->c1 * cm; a.cin = a.c0 + a.c1; a.split = split ? 1 : 0;
     a.n = d->n; a.h = d->h; a.w = d->w; a.ho = d->ho; a.wo = d->wo; a.cout = d->cout;
     a.kh = d->kh; a.kw = d->kw; a.sh = d->stride_h; a.sw = d->stride_w; a.ph = d->pad_h; a.pw = d->pad_w;
     a.K = d->kh * d->kw * a.cin; a.npix = (int)npix; a.howo = d->ho * d->wo;
     a.in_swish = d->in_swish; a.act = d->act; a.res_mod = d->res_mod;
-    const int bk = d->dtype == MNET_F16 ? 64 : 32;
+    const int bk = d->dtype == MNET_F32 ? 32 : 64;
     a.ktiles = (a.K + bk - 1) / bk; a.tilesC = 0; a.ntiles = 0;
     return MNET_OK;
 }
@@ -396,7 +488,7 @@ static int conv_resolve(const mnet_conv_desc* d, int32_t algo, const ConvArgs& a
     }
     if (algo == MNET_CONV_ALGO_AUTO && conv_skinny_eligible(a, d->dtype)) return MNET_CONV_ALGO_SKINNY;
     if (algo >= MNET_CONV_ALGO_LDS_DMA && !dma_ok)
-        return mnet_fail(MNET_E_ARG, "conv: LDS-DMA algo needs f16, cin %% 64 == 0, cout >= 64, cout %% 8 == 0 and no input transform");
+        return mnet_fail(MNET_E_ARG, "conv: LDS-DMA algo needs f16 (cin %% 64 == 0) or split-half (cin %% 32 == 0), cout >= 64, cout %% 8 == 0 and no input transform");
     if (algo >= MNET_CONV_ALGO_DMA_CFG0) return algo;
     if (algo != MNET_CONV_ALGO_REG_STAGED && strip >= 0 && !no_strip) return MNET_CONV_ALGO_STRIP_CFG0 + strip;
     if (dma_ok && algo != MNET_CONV_ALGO_REG_STAGED) return MNET_CONV_ALGO_DMA_CFG0 + conv_dma_pick(a);
@@ -420,6 +512,7 @@ extern "C" int mnet_conv2d_nhwc_ex(const mnet_conv_desc* d, int32_t algo, void* 
     if (k >= MNET_CONV_ALGO_STRIP_CFG0) return launch_conv_strip(a, st, k - MNET_CONV_ALGO_STRIP_CFG0);
     if (k >= MNET_CONV_ALGO_DMA_CFG0) return launch_conv_dma(a, st, k - MNET_CONV_ALGO_DMA_CFG0);
     if (k == MNET_CONV_ALGO_SKINNY) return launch_conv_skinny(a, st);
+    if (d->dtype == MNET_F16X2) return launch_dtype<hs>(a, st);
     return d->dtype == MNET_F16 ? launch_dtype<f16>(a, st) : launch_dtype<float>(a, st);
 }
 

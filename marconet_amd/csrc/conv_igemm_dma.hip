@@ -25,7 +25,11 @@
 // MF = 16: v_mfma_f32_16x16x32_f16 — production;
 // MF = 32: v_mfma_f32_32x32x16_f16 — experimental (half the matrix instructions per slab; not faster here: the kernel is
 //          power/clock limited)
-template <int BC, int BP, int WC, int WP, int STAGES, int MF = 16, int DBG = 0>
+// X3: split-half launch (MNET_F16X2, the fp16x3 precision mode).  The DMA side is unchanged — the tensors are walked as f16
+//     with twice the channels, so one 128-byte slab row is one 32-channel block: chunks 0-3 hi, chunks 4-7 lo — and every slab is
+//     multiplied three times (hi*hi, hi*lo, lo*hi) from the one LDS image: 1.5x the MFMA work per slab, per barrier and per byte
+//     moved of the f16 kernel.
+template <int BC, int BP, int WC, int WP, int STAGES, int MF = 16, int DBG = 0, bool X3 = false>
 __global__ void __launch_bounds__(WC * WP * 64, WC * WP / 4) conv_dma_kernel(const ConvArgs p) {
     constexpr int NW = WC * WP;                          // waves per workgroup (8 or 16)
     constexpr int FC = BC / WC / 16, FP = BP / WP / 16;
@@ -34,6 +38,7 @@ __global__ void __launch_bounds__(WC * WP * 64, WC * WP / 4) conv_dma_kernel(con
     constexpr int STAGE = (BC + BP) * 128;
     constexpr unsigned OOB = 0x80000000u;                // beyond every num_records used below
     static_assert(NW == 8 || NW == 16, "8 or 16 waves");
+    static_assert(!X3 || MF == 16, "the split-half form uses v_mfma_f32_16x16x32_f16");
     static_assert(WJ >= 1 && XJ >= 1 && WJ * 8 * NW == BC && XJ * 8 * NW == BP, "tile / wave-count mismatch");
     static_assert(STAGES == 2 || ((STAGES == 3 || STAGES == 4) && NDMA >= 4 && NDMA <= 6), "vmcnt immediates below cover 4-6 DMAs per slab, up to 3 slabs in flight");
     static_assert((BC / WC) % 64 == 0 && (BP / WP) % 32 == 0, "the channel permutation works on 64-channel blocks of a wave tile");
@@ -218,6 +223,37 @@ __global__ void __launch_bounds__(WC * WP * 64, WC * WP / 4) conv_dma_kernel(con
         }
     };
 
+    // split-half slab: 32 channels, hi halves in chunks 0-3 and lo halves in chunks 4-7 of every row; x*w = hi*hi + hi*lo + lo*hi
+    // (lo*lo is below fp32 resolution) — the same fp32 accumulators take all three products
+    auto compute_x3 = [&](int stage) __attribute__((always_inline)) {
+        const unsigned char* sw_ = smem + stage * STAGE;
+        const unsigned char* sx_ = sw_ + BC * 128;
+        u32x4 a[FC], bh[FP], bl[FP];
+#pragma unroll
+        for (int f = 0; f < FC; ++f) a[f] = *reinterpret_cast<const u32x4*>(sw_ + swz_dma(wc * (BC / WC) + f * 16 + l16, g));
+#pragma unroll
+        for (int f = 0; f < FP; ++f) bh[f] = *reinterpret_cast<const u32x4*>(sx_ + swz_dma(wp * (BP / WP) + f * 16 + l16, g));
+#pragma unroll
+        for (int fa = 0; fa < FC; ++fa)
+#pragma unroll
+            for (int fb = 0; fb < FP; ++fb)
+                acc[fa][fb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bitcast<f16x8>(a[fa]), bitcast<f16x8>(bh[fb]), acc[fa][fb], 0, 0, 0);
+#pragma unroll
+        for (int f = 0; f < FP; ++f) bl[f] = *reinterpret_cast<const u32x4*>(sx_ + swz_dma(wp * (BP / WP) + f * 16 + l16, 4 + g));
+#pragma unroll
+        for (int fa = 0; fa < FC; ++fa)
+#pragma unroll
+            for (int fb = 0; fb < FP; ++fb)
+                acc[fa][fb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bitcast<f16x8>(a[fa]), bitcast<f16x8>(bl[fb]), acc[fa][fb], 0, 0, 0);
+#pragma unroll
+        for (int f = 0; f < FC; ++f) a[f] = *reinterpret_cast<const u32x4*>(sw_ + swz_dma(wc * (BC / WC) + f * 16 + l16, 4 + g));
+#pragma unroll
+        for (int fa = 0; fa < FC; ++fa)
+#pragma unroll
+            for (int fb = 0; fb < FP; ++fb)
+                acc[fa][fb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bitcast<f16x8>(a[fa]), bitcast<f16x8>(bh[fb]), acc[fa][fb], 0, 0, 0);
+    };
+
     // wait until at most `keep` (1 or 2) of this wave's slabs are still in flight: vmcnt(keep * NDMA), an immediate
     auto wait_keep = [&](int keep) {
         if (keep >= 2) { if constexpr (NDMA == 6) VMCNT(12); else if constexpr (NDMA == 5) VMCNT(10); else VMCNT(8); }
@@ -260,8 +296,8 @@ __global__ void __launch_bounds__(WC * WP * 64, WC * WP / 4) conv_dma_kernel(con
             __builtin_amdgcn_s_barrier();                // ... and every wave is done reading the stage refilled next
             asm volatile("" ::: "memory");
             issue_hot();
-            compute_half(c_stage, 0);
-            compute_half(c_stage, 1);
+            if constexpr (X3) compute_x3(c_stage);
+            else { compute_half(c_stage, 0); compute_half(c_stage, 1); }
             c_stage = c_stage == STAGES - 1 ? 0 : c_stage + 1;
         }
         // tail iterations: the slab issued belongs to this workgroup's NEXT tile (set-up + first-slab latency overlap the
@@ -273,15 +309,15 @@ __global__ void __launch_bounds__(WC * WP * 64, WC * WP / 4) conv_dma_kernel(con
             __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");
             inflight += issue_next() - 1;
-            compute_half(c_stage, 0);
-            compute_half(c_stage, 1);
+            if constexpr (X3) compute_x3(c_stage);
+            else { compute_half(c_stage, 0); compute_half(c_stage, 1); }
             c_stage = c_stage == STAGES - 1 ? 0 : c_stage + 1;
         }
         if constexpr (DBG >= 3) { stamp[2] = wall_clock64(); cyc = (long long)__builtin_readcyclecounter() - cyc; }
 
         int co0, pix0;
         tile_coords(c_v, co0, pix0);
-        dma_epilogue<BC, BP, WC, WP, MF, DBG, FC, FP>(p, acc, acc32, co0, pix0, wc, wp, lane);
+        dma_epilogue<BC, BP, WC, WP, MF, DBG, FC, FP, X3>(p, acc, acc32, co0, pix0, wc, wp, lane);
         drain = true;
 
         if constexpr (DBG >= 3) {       // DIAGNOSTIC: overwrite part of the output with this tile's time stamps
@@ -299,10 +335,10 @@ __global__ void __launch_bounds__(WC * WP * 64, WC * WP / 4) conv_dma_kernel(con
     }
 }
 
-template <int BC, int BP, int WC, int WP, int STAGES, int MF = 16, int DBG = 0>
+template <int BC, int BP, int WC, int WP, int STAGES, int MF = 16, int DBG = 0, bool X3 = false>
 static int launch_dma_cfg(const ConvArgs& a, hipStream_t st) {
     constexpr int LDS = STAGES * (BC + BP) * 128;
-    auto kern = conv_dma_kernel<BC, BP, WC, WP, STAGES, MF, DBG>;
+    auto kern = conv_dma_kernel<BC, BP, WC, WP, STAGES, MF, DBG, X3>;
     static thread_local DeviceOnce attr_once;      // per instantiation, per thread, per device
     if (!attr_once.done()) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
@@ -330,6 +366,19 @@ static int launch_dma_cfg(const ConvArgs& a, hipStream_t st) {
 // ids 7-9: v_mfma_f32_32x32x16_f16 forms (fp32 sums associate differently).
 // ids 11-15: DIAGNOSTIC builds that produce wrong results on purpose (tools/wg_timeline.py, tools/conv_bench.py).
 static int launch_dma_id(int id, const ConvArgs& a, hipStream_t st) {
+    if (a.split) {      // split-half (fp16x3) instantiations of the production tile configurations
+        switch (id) {
+            case 0: return launch_dma_cfg<256, 256, 4, 4, 2, 16, 0, true>(a, st);
+            case 1: return launch_dma_cfg<256, 128, 4, 2, 3, 16, 0, true>(a, st);
+            case 2: return launch_dma_cfg<128, 256, 2, 4, 3, 16, 0, true>(a, st);
+            case 3: return launch_dma_cfg<64, 256, 1, 8, 3, 16, 0, true>(a, st);
+            case 4: return launch_dma_cfg<128, 512, 2, 8, 2, 16, 0, true>(a, st);
+            case 5: return launch_dma_cfg<64, 512, 1, 8, 2, 16, 0, true>(a, st);
+            case 6: return launch_dma_cfg<256, 256, 2, 4, 2, 16, 0, true>(a, st);
+            case 10: return launch_dma_cfg<128, 128, 2, 4, 4, 16, 0, true>(a, st);
+            default: return mnet_fail(MNET_E_ARG, "conv: LDS-DMA tile configuration %d has no split-half form", id);
+        }
+    }
     switch (id) {
         case 0: return launch_dma_cfg<256, 256, 4, 4, 2>(a, st);
         case 1: return launch_dma_cfg<256, 128, 4, 2, 3>(a, st);
@@ -368,7 +417,8 @@ int launch_conv_dma(const ConvArgs& a, hipStream_t st, int cfg) {
 
 // eligibility of the LDS-DMA path (see header comment); the caller falls back to the register-staged kernel
 bool conv_dma_eligible(const ConvArgs& a, int dtype) {
-    if (dtype != MNET_F16 || a.in_scale || a.act > MNET_ACT_LRELU_SQRT2) return false;
+    if ((dtype != MNET_F16 && dtype != MNET_F16X2) || a.in_scale || a.act > MNET_ACT_LRELU_SQRT2) return false;
+    if (dtype == MNET_F16X2 && a.cout % 32 != 0) return false;          // (a.c0 / a.cin / a.K are physical here: f16 view, doubled)
     if (a.cin % 64 != 0 || a.c0 % 64 != 0 || a.cout < 64 || a.cout % 8 != 0 || a.kh * a.kw > 32 || a.kh > 8 || a.kw > 8) return false;
     // 31-bit buffer offsets: a pixel tile may touch ceil(256/howo)+1 images
     const long long imgs = 512 / a.howo + 2;   // largest pixel tile is 512

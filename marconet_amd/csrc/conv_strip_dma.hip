@@ -257,7 +257,7 @@ int conv_strip_pick(const ConvArgs& a, int dtype, bool explicit_request) {
     // 256x256 tiles: measured neutral (89.8 + 5.1 vs 94.5 ms per bench step; 128-VGPR budget of its 16 waves is exhausted,
     // 20 spills) — AUTO keeps the per-tap kernel there unless MNET_STRIP_256=1; the 64x512 tile (8 waves) gains 20 %.
     static const bool auto256 = [] { const char* e = getenv("MNET_STRIP_256"); return e && atoi(e) != 0; }();
-    if (!conv_dma_eligible(a, dtype)) return -1;
+    if (dtype != MNET_F16 || !conv_dma_eligible(a, dtype)) return -1;      // (split-half launches take the per-tap LDS-DMA kernel)
     if (a.cout >= 256 && !explicit_request && !auto256) return -1;
     if (a.kh != 3 || a.kw != 3 || a.sh != 1 || a.sw != 1 || a.ph != 1 || a.pw != 1 || a.c1 != 0 || a.x1) return -1;
     if (a.ho != a.h || a.wo != a.w) return -1;

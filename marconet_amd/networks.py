@@ -16,19 +16,21 @@ import torch.nn as nn
 
 from . import ops
 from .glyphs import GlyphTables
-from .packing import (PackCache, default_precision, equal_linear_scale, pack_conv_weight, pack_vec, sn_fold,
-                      torch_dtype)
+from .packing import (PRECISIONS, SPLIT_DTYPE, PackCache, default_precision, equal_linear_scale, pack_conv_weight, pack_vec,
+                      rgb_pad, sn_fold, torch_dtype)
 from .resnet import resnet45stride as resnet45
 from .textvit_arch import TextViT as TextEncoder
 
-RGB_PAD = 8      # 3-channel tensors are carried with 8 channels (one 16-byte fp16 chunk)
+RGB_PAD = 8      # 3-channel tensors are carried with 8 channels (one 16-byte fp16 chunk); 32 in the split-half mode (rgb_pad)
 
 
 class _Precision:
     def set_precision(self, precision):
-        """'fp32' (parity mode, ≤1e-3 vs the CPU reference) or 'fp16' (throughput mode; fp32 accumulate/statistics)."""
-        if precision not in ("fp32", "fp16"):
-            raise ValueError("precision must be 'fp32' or 'fp16'")
+        """'fp32' (parity mode, exact fp32 MFMA), 'fp16x3' (split-half storage, three fp16 MFMA products per multiply:
+        meets the same ≤1e-3 / bit-exact-argmax bar at several times the fp32 mode's rate) or 'fp16' (one half per element:
+        fastest, ~1e-2 deviation).  Accumulation, statistics and the TextViT are fp32 in every mode."""
+        if precision not in PRECISIONS:
+            raise ValueError("precision must be one of %s" % ", ".join(PRECISIONS))
         self.precision = precision
         for m in self.children():
             if hasattr(m, "precision"):
@@ -52,7 +54,8 @@ class TextContextEncoderV2(nn.Module, _Precision):
     def forward(self, lq):
         with torch.no_grad(), ops.on_device(lq):
             self.resnet.precision = self.precision
-            x = ops.nchw_to_nhwc(lq.contiguous().float(), torch_dtype(self.precision), c_ld=8)
+            dtype = torch_dtype(self.precision)
+            x = ops.nchw_to_nhwc(lq.contiguous().float(), dtype, c_ld=rgb_pad(dtype))
             feat = self.resnet.forward_nhwc(x)
             feat = ops.convert(feat, torch.float32)          # the ViT always runs in fp32
             return self.transformer.forward_nhwc(feat)
@@ -174,9 +177,9 @@ class TextGenerator(nn.Module):
         def torgb(tr):
             mc = tr.conv
             w = mc.scale * mc.weight.detach()[0]                                   # [3,Cin,1,1]
-            return dict(cin=mc.in_channel, w=pack_conv_weight(w, dtype, cout_mult=RGB_PAD),
+            return dict(cin=mc.in_channel, w=pack_conv_weight(w, dtype, cout_mult=rgb_pad(dtype)),
                         mod_w=f(mc.modulation.weight.detach() * mc.modulation.scale), mod_b=f(mc.modulation.bias),
-                        bias=pack_vec(tr.bias, RGB_PAD))
+                        bias=pack_vec(tr.bias, rgb_pad(dtype)))
 
         pk["conv1"] = styled(self.conv1)
         pk["rgb1"] = torgb(self.to_rgb1)
@@ -217,7 +220,7 @@ class TextGenerator(nn.Module):
         s = S[:, L["mod_off"]:L["mod_off"] + L["cin"]].contiguous()
         if skip is not None:
             skip = ops.upsample2x(skip)                                        # :318-319
-        return ops.conv2d(x, L["w"], RGB_PAD, in_scale=s, bias=L["bias"], residual=skip, act=ops.ACT_TANH)
+        return ops.conv2d(x, L["w"], L["w"].shape[0], in_scale=s, bias=L["bias"], residual=skip, act=ops.ACT_TANH)
 
     def forward_nhwc(self, styles, labels, need_image=True, style_index=None):
         """→ (image NHWC [N,128,128c,8], prior64 NHWC [N,64,64c,256], prior32 NHWC [N,32,32c,512]).
@@ -366,10 +369,9 @@ class TSPSRNet(nn.Module, _Precision):
         pk = {}
 
         def sn(name, m, cout_mult=4):
-            w = sn_fold(m.weight_orig, m.weight_u, m.weight_v)
-            cp = (m.out_channels + cout_mult - 1) // cout_mult * cout_mult
-            pk[name] = dict(w=pack_conv_weight(w, dtype, cout_mult=cout_mult), b=pack_vec(m.bias, cp), cout=cp,
-                            stride=(m.stride, m.stride))
+            w = pack_conv_weight(sn_fold(m.weight_orig, m.weight_u, m.weight_v), dtype, cout_mult=cout_mult)
+            cp = w.shape[0]                                    # padded cout (whole 32-channel blocks in the split-half mode)
+            pk[name] = dict(w=w, b=pack_vec(m.bias, cp), cout=cp, stride=(m.stride, m.stride))
 
         def res(name, m):
             sn(name + ".conv1", m.conv1)
@@ -388,9 +390,10 @@ class TSPSRNet(nn.Module, _Precision):
             sn(name + ".2", getattr(self, name)[2])
         sn("conv_up.1", self.conv_up[1]); res("conv_up.3", self.conv_up[3]); sn("conv_up.4", self.conv_up[4])
         sn("conv_final.0", self.conv_final[0]); sn("conv_final.3", self.conv_final[3])
-        res("conv_final.5", self.conv_final[5]); sn("conv_final.6", self.conv_final[6], cout_mult=RGB_PAD)
+        res("conv_final.5", self.conv_final[5]); sn("conv_final.6", self.conv_final[6], cout_mult=rgb_pad(dtype))
         m6 = self.conv_final[6]                       # the same layer for the dedicated 64 → 3 kernel: [3][3][3][64], bias [3]
-        pk["conv_final.6.rgb"] = (sn_fold(m6.weight_orig, m6.weight_u, m6.weight_v).permute(0, 2, 3, 1).contiguous().to(dtype),
+        rgb_dt = torch.float32 if dtype == SPLIT_DTYPE else dtype          # (the split-half mode runs this 64 → 3 layer in fp32)
+        pk["conv_final.6.rgb"] = (sn_fold(m6.weight_orig, m6.weight_u, m6.weight_v).permute(0, 2, 3, 1).contiguous().to(rgb_dt),
                                   m6.bias.detach().float().contiguous())
         res("conv_32_fuse.0", self.conv_32_fuse[0]); res("conv_64_fuse.0", self.conv_64_fuse[0])
         return pk
@@ -477,7 +480,7 @@ class TSPSRNet(nn.Module, _Precision):
         with torch.no_grad(), ops.on_device(lq):
             pk = self._cache.get(self, self.precision, self._build)
             dtype = torch_dtype(self.precision)
-            x = ops.nchw_to_nhwc(lq.contiguous().float(), dtype, c_ld=8)
+            x = ops.nchw_to_nhwc(lq.contiguous().float(), dtype, c_ld=rgb_pad(dtype))
             f32 = self._c(pk, "conv_first_32.0", x, ops.ACT_LRELU)                               # :412
             f16 = self._c(pk, "conv_first_16.0", f32, ops.ACT_LRELU)                             # :413
             f8 = self._c(pk, "conv_first_8.2", self._c(pk, "conv_first_8.0", f16, ops.ACT_LRELU))  # :414

@@ -1,7 +1,8 @@
 """Tensor-level wrappers over the C-ABI.  PyTorch is plumbing only: it owns the device memory
 (caching allocator) and the current HIP stream; every arithmetic op below is a hand-written gfx950 kernel.
 
-Activations are NHWC torch tensors of dtype float32 or float16, shape [N,H,W,C].
+Activations are NHWC torch tensors of shape [N,H,W,C] and dtype float32, float16 or — the split-half storage of the fp16x3
+mode (MNET_F16X2) — packing.SPLIT_DTYPE (a 4-byte tag: a (hi, lo) pair of halves per logical element, C % 32 == 0).
 """
 import ctypes
 import os
@@ -10,7 +11,8 @@ import torch
 
 from . import _lib
 from ._lib import (ACT_GELU, ACT_LRELU, ACT_LRELU_SQRT2, ACT_NONE, ACT_RELU, ACT_SIGMOID, ACT_TANH, MNET_F16,
-                   MNET_F32, ConvDesc)
+                   MNET_F16X2, MNET_F32, ConvDesc)
+from .packing import SPLIT_DTYPE
 
 __all__ = ["conv2d", "linear", "nchw_to_nhwc", "nhwc_to_nchw", "upsample2x", "affine_act", "groupnorm_affine",
            "adain_crop_concat", "adain_crop_concat_gn", "glyph_scatter_affine", "layernorm", "token_mix", "attention", "pixelnorm",
@@ -23,6 +25,8 @@ def _dt(t):
         return MNET_F32
     if t.dtype == torch.float16:
         return MNET_F16
+    if t.dtype == SPLIT_DTYPE:          # split half (fp16x3 mode): (hi, lo) per logical element, tagged as complex32
+        return MNET_F16X2
     raise TypeError("marconet_amd: unsupported dtype %s" % t.dtype)
 
 
@@ -373,14 +377,15 @@ def sr_postprocess(y_nhwc, u8=True):
 
 
 def conv3x3_rgb(x, wgt, bias, act=ACT_TANH, nhwc=True, nchw=False):
-    """conv_final.6 (+ tanh): x NHWC [N,H,W,64]; wgt [3,3,3,64] same dtype; bias fp32 [3] → NHWC [N,H,W,8] (same dtype)
-    and/or fp32 NCHW [N,3,H,W]; returns (y_nhwc or None, y_nchw or None)."""
+    """conv_final.6 (+ tanh): x NHWC [N,H,W,64]; wgt [3,3,3,64] same dtype (fp32 for a split-half x); bias fp32 [3] → NHWC
+    [N,H,W,8] (same dtype; fp32 for a split-half x) and/or fp32 NCHW [N,3,H,W]; returns (y_nhwc or None, y_nchw or None)."""
     lib = _lib.load()
     _need_cuda(x, wgt, bias)
     n, h, w, c = x.shape
-    if wgt.dtype != x.dtype or wgt.numel() != 3 * 9 * c:
+    odt = torch.float32 if x.dtype == SPLIT_DTYPE else x.dtype       # split-half input: fp32 weights, fp32 outputs
+    if wgt.dtype != odt or wgt.numel() != 3 * 9 * c:
         raise RuntimeError("conv3x3_rgb: weight dtype/shape mismatch")
-    y1 = torch.empty((n, h, w, 8), dtype=x.dtype, device=x.device) if nhwc else None
+    y1 = torch.empty((n, h, w, 8), dtype=odt, device=x.device) if nhwc else None
     y2 = torch.empty((n, 3, h, w), dtype=torch.float32, device=x.device) if nchw else None
     _lib.check(lib.mnet_conv3x3_rgb(_p(x), _dt(x), n, h, w, c, _p(wgt), _p(bias), act, _p(y1), _p(y2), _stream()), "mnet_conv3x3_rgb")
     return y1, y2

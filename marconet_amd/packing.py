@@ -8,19 +8,62 @@ weight modulation, models/networks.py:284-290).
 """
 import math
 import os
+import warnings
 
 import torch
+
+# MNET_F16X2 ("split half", include/marconet_hip.h) tensors are tagged with torch.complex32: 4 bytes per LOGICAL element — a
+# (hi, lo) pair of halves — so shapes, slicing along the outer dimensions, torch.cat / index_select over images and the caching
+# allocator all work on logical NHWC shapes.  PyTorch never does arithmetic on them (only this package's kernels read the
+# bytes; the hi / lo halves are blocked per 32 channels, not interleaved per element).
+warnings.filterwarnings("ignore", message="ComplexHalf support is experimental")
+SPLIT_DTYPE = torch.complex32
+SPLIT_WSCALE = 256.0          # MNET_SPLIT_WSCALE: split-half conv weights hold hi/lo of 256*W (the conv rescales by 2^-8)
+PRECISIONS = ("fp32", "fp16", "fp16x3")
 
 
 def default_precision():
     p = os.environ.get("MARCONET_PRECISION", "fp32").lower()
-    if p not in ("fp32", "fp16"):
-        raise ValueError("MARCONET_PRECISION must be fp32 or fp16, got %r" % p)
+    if p not in PRECISIONS:
+        raise ValueError("MARCONET_PRECISION must be one of %s, got %r" % (", ".join(PRECISIONS), p))
     return p
 
 
 def torch_dtype(precision):
-    return torch.float32 if precision == "fp32" else torch.float16
+    """storage dtype of the activations / conv weights of a precision mode:
+    fp32 — exact fp32 MFMA (parity mode); fp16 — one half per element (throughput mode, ~1e-2 deviation);
+    fp16x3 — split half (hi, lo) per element, x*w = hi*hi + hi*lo + lo*hi on the fp16 MFMA: fp32-class accuracy (meets the
+    1e-3 parity bar, argmax bit-exact) at a third of the fp16 MFMA rate instead of the fp32 MFMA's sixteenth."""
+    if precision not in PRECISIONS:
+        raise ValueError("precision must be one of %s" % ", ".join(PRECISIONS))
+    return {"fp32": torch.float32, "fp16": torch.float16, "fp16x3": SPLIT_DTYPE}[precision]
+
+
+def rgb_pad(dtype):
+    """channel count 3-channel tensors are carried with: one 16-byte chunk of halves / floats, or one 32-channel split block"""
+    return 32 if dtype == SPLIT_DTYPE else 8
+
+
+def split_halves(t):
+    """fp32 tensor [..., C] (C % 32 == 0) → split-half tensor of the same logical shape (host-side packing of weights):
+    per 32-channel block 32 hi halves then 32 lo halves, hi = f16(v), lo = f16(v - hi)"""
+    if t.shape[-1] % 32 != 0:
+        raise ValueError("split-half tensors need a multiple of 32 channels, got %d" % t.shape[-1])
+    t = t.detach().float().contiguous()
+    if t.numel() and float(t.abs().max()) > 65000.0:
+        raise OverflowError("value %.3g does not fit the half range of the fp16x3 mode" % float(t.abs().max()))
+    hi = t.to(torch.float16)
+    lo = (t - hi.float()).to(torch.float16)
+    blk = t.shape[:-1] + (t.shape[-1] // 32, 32)
+    both = torch.stack((hi.reshape(blk), lo.reshape(blk)), dim=-2).contiguous()          # [..., C/32, 2, 32] halves
+    return both.view(SPLIT_DTYPE).reshape(t.shape)
+
+
+def unsplit_halves(t):
+    """inverse of split_halves (tests / debugging): split-half tensor → fp32"""
+    c = t.shape[-1]
+    h = t.contiguous().view(torch.float16).reshape(t.shape[:-1] + (c // 32, 2, 32)).float()
+    return (h[..., 0, :] + h[..., 1, :]).reshape(t.shape)
 
 
 def _round_up(v, m):
@@ -30,11 +73,15 @@ def _round_up(v, m):
 def pack_conv_weight(w, dtype, cin_mult=8, cout_mult=4):
     """w [O,I,KH,KW] fp32 → contiguous [O_pad,KH,KW,I_pad] in ``dtype`` (zero padded)."""
     o, i, kh, kw = w.shape
+    if dtype == SPLIT_DTYPE:            # whole 32-channel blocks on both sides
+        cin_mult, cout_mult = max(cin_mult, 32), max(cout_mult, 32)
     op, ip = _round_up(o, cout_mult), _round_up(i, cin_mult)
     if op != o or ip != i:
         wp = torch.zeros((op, ip, kh, kw), dtype=w.dtype, device=w.device)
         wp[:o, :i] = w
         w = wp
+    if dtype == SPLIT_DTYPE:
+        return split_halves(w.permute(0, 2, 3, 1).contiguous() * SPLIT_WSCALE)
     return w.permute(0, 2, 3, 1).contiguous().to(dtype)
 
 

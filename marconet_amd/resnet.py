@@ -10,7 +10,7 @@ import torch
 import torch.nn as nn
 
 from . import ops
-from .packing import PackCache, default_precision, pack_conv_weight, torch_dtype
+from .packing import PackCache, default_precision, pack_conv_weight, rgb_pad, torch_dtype
 
 
 def _conv(cin, cout, k, stride=1):
@@ -84,7 +84,8 @@ class ResNet(nn.Module):
     def forward(self, x):
         """NCHW fp32 in → NCHW fp32 out, like the reference (models/resnet.py:63-71)."""
         with torch.no_grad(), ops.on_device(x):
-            h = ops.nchw_to_nhwc(x.contiguous().float(), torch_dtype(self.precision), c_ld=8)
+            dtype = torch_dtype(self.precision)
+            h = ops.nchw_to_nhwc(x.contiguous().float(), dtype, c_ld=rgb_pad(dtype))
             return ops.nhwc_to_nchw(self.forward_nhwc(h))
 
 

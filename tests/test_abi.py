@@ -30,7 +30,7 @@ def test_library_exports_every_declared_symbol():
         assert n in _lib.SYMBOLS, "header symbol %s has no ctypes binding" % n
         assert getattr(lib, n) is not None
     assert set(_lib.SYMBOLS) == set(names)
-    assert lib.mnet_abi_version() == 1
+    assert lib.mnet_abi_version() == _lib.ABI_VERSION == 2
 
 
 def test_conv_desc_layout_matches_c():
@@ -43,8 +43,8 @@ def test_conv_desc_layout_matches_c():
 int main(void){ printf("%zu %zu %zu %zu %zu %zu\n", sizeof(mnet_conv_desc), offsetof(mnet_conv_desc, x1),
   offsetof(mnet_conv_desc, wgt), offsetof(mnet_conv_desc, in_scale), offsetof(mnet_conv_desc, residual), offsetof(mnet_conv_desc, y)); return 0; }
 '''
-    d = os.path.join(ROOT, "oracle", "_ref")
-    os.makedirs(d, exist_ok=True)
+    import tempfile
+    d = tempfile.mkdtemp(prefix="mnet_abi_")
     cpath, exe = os.path.join(d, "abi_probe.c"), os.path.join(d, "abi_probe")
     open(cpath, "w").write(code)
     subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), cpath, "-o", exe])

@@ -192,6 +192,64 @@ def test_fp16_throughput_mode_deviation(nets, ckpts):
             m.set_precision("fp32")
 
 
+@pytest.mark.parametrize("name", ["grid", "full16", "edges"])
+def test_fp16x3_mode_meets_the_parity_bar(name, nets, ckpts, golden):
+    """the split-half throughput mode (three fp16 MFMA products per multiply) against the north-star bar itself:
+    SR <= 1e-3 max-abs vs the CPU oracle AND vs the real reference's golden samples, character indices bit-exact"""
+    lq, locs, labels = cases.sr_input(name)
+    r = O.end_to_end(ckpts[0], ckpts[1], ckpts[2], lq, labels, locs)
+    try:
+        for m in nets:
+            m.set_precision("fp16x3")
+        logits, elocs, w = nets[0](lq.to(DEV))
+        assert torch.equal(logits.argmax(-1).cpu(), r["logits"].argmax(-1))
+        _note("enc.fp16x3.%s.logits.maxabs" % name, _err(logits, r["logits"]))
+        _note("enc.fp16x3.%s.w.maxabs" % name, _err(w, r["w"]))
+        assert _err(logits, r["logits"]) <= TOL and _err(w, r["w"]) <= TOL and _err(elocs, r["locs"]) <= TOL
+        p64, p32 = [], []
+        for b, lab in enumerate(labels):
+            img, a, c = nets[1](styles=w[b:b + 1].repeat(lab.shape[0], 1), labels=lab, noise=None)
+            p64.append(a)
+            p32.append(c)
+            if b == 0:
+                _note("gan.fp16x3.%s.image.maxabs" % name, _err(img, r["prior_images"][0]))
+                _note("gan.fp16x3.%s.prior64.maxabs" % name, _err(a, r["p64"][0]))
+                assert _err(img, r["prior_images"][0]) <= TOL and _err(a, r["p64"][0]) <= TOL
+        y = nets[2](lq.to(DEV), p64, p32, locs.to(DEV))
+        e = _err(y, r["sr"])
+        _note("sr.fp16x3.%s.chain.maxabs" % name, e)
+        assert torch.isfinite(y).all() and e <= TOL
+        assert np.abs(cases.sample_map(y.cpu(), "sr").numpy() - golden["sr.%s.out_s" % name]).max() <= TOL
+    finally:
+        for m in nets:
+            m.set_precision("fp32")
+
+
+def test_fp16x3_batched_driver_and_batch_invariance(nets, ckpts):
+    """forward_batch in the fp16x3 mode on bench-shaped strips vs the oracle, and a batch == its halves bit for bit"""
+    from marconet_amd.pipeline import MarconetPipeline
+    counts, widths = [16, 7, 16, 12], [512, 512, 400, 512]
+    lq = synth.make_lq(151, 4, widths)
+    labels = [synth.make_labels(160 + b, c) for b, c in enumerate(counts)]
+    locs = synth.make_locs(counts, widths, max_glyphs=16)
+    pipe = MarconetPipeline(*nets, precision="fp16x3")
+    try:
+        y = pipe.forward_batch(lq.to(DEV), labels, locs)
+        worst = 0.0
+        for b in range(4):
+            r = O.end_to_end(ckpts[0], ckpts[1], ckpts[2], lq[b:b + 1], [labels[b]], locs[b:b + 1])
+            worst = max(worst, _err(y[b:b + 1], r["sr"]))
+        _note("sr.fp16x3.forward_batch.bench_shape.maxabs", worst)
+        assert worst <= TOL
+        lo = pipe.forward_batch(lq[:2].to(DEV), labels[:2], locs[:2])
+        hi = pipe.forward_batch(lq[2:].to(DEV), labels[2:], locs[2:])
+        assert torch.equal(y[:2], lo) and torch.equal(y[2:], hi)
+        u8 = pipe.forward_batch(lq.to(DEV), labels, locs, output="u8_bgr")
+        assert u8.dtype == torch.uint8 and u8.shape == (4, 128, 2048, 3)
+    finally:
+        pipe.set_precision("fp32")
+
+
 def test_error_behaviour(nets):
     """errors surface as Python exceptions so test_sr.py's try/except…continue (:181-190) keeps working"""
     styles = synth.make_styles(1, 2).to(DEV)
