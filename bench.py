@@ -274,24 +274,22 @@ def main():
         pipe.need_prior_image = True
         secondary = {"images_per_s_without_prior_image": round(total_images * a.steps / dt2, 3), "ms_per_step": round(dt2 / a.steps * 1e3, 3),
                      "note": "opt-in MarconetPipeline(need_prior_image=False): TSPGAN stops at the 64-px level; SR output identical"}
-        if world == 1:
-            kb = min(B, 16)
-            for prec in ("fp16", "fp16x3", "fp32"):
-                if prec == a.precision:
-                    continue
-                try:
-                    pipe.set_precision(prec)
-                except ValueError:
-                    continue
-                kk = kb if prec == "fp32" else min(B, 64)
-                pipe.forward_batch(lq[:kk], labels[:kk], locs[:kk])
-                torch.cuda.synchronize()
-                t0 = time.perf_counter()
-                pipe.forward_batch(lq[:kk], labels[:kk], locs[:kk])
-                torch.cuda.synchronize()
-                secondary["%s_mode_images_per_s" % prec] = round(kk / (time.perf_counter() - t0), 3)
-                secondary["%s_mode_batch" % prec] = kk
-            pipe.set_precision(a.precision)
+        # the other precision modes on the same batch (fp32: a 16-image slice — 54 images/s): the mode that meets the parity bar
+        # (fp16x3, or fp32) is always reported next to the fp16 storage mode, with its measured deviation under "parity" below
+        for prec in ("fp16x3", "fp16", "fp32"):
+            if prec == a.precision:
+                continue
+            pipe.set_precision(prec)
+            kk = min(B, 16) if prec == "fp32" else B
+            step_k = (lambda: pipe.forward_batch(lq[:kk], labels[:kk], locs[:kk])) if kk != B else step
+            step_k()
+            dtk, _, _ = timed(step_k, fence, 1 if prec == "fp32" else a.steps, world, dev)
+            n_steps = 1 if prec == "fp32" else a.steps
+            secondary["%s_mode_images_per_s" % prec] = round((total_images if kk == B else kk * world) * n_steps / dtk, 3)
+            secondary["%s_mode_batch_per_gpu" % prec] = kk
+        pipe.set_precision(a.precision)
+        secondary["modes"] = ("fp32: exact fp32 MFMA (parity mode); fp16x3: split-half storage, hi*hi + hi*lo + lo*hi on the fp16 MFMA "
+                              "(meets the 1e-3 bar, see parity); fp16: one half per element (BASELINE configs[1]'s storage type)")
 
     out = {
         "metric": {"sr": "SR images/sec (32x512 LR -> 128x2048 SR)", "gan": "TSPGAN glyph images/sec (128x128 structure prior)",

@@ -205,7 +205,7 @@ def test_fp16x3_mode_meets_the_parity_bar(name, nets, ckpts, golden):
         assert torch.equal(logits.argmax(-1).cpu(), r["logits"].argmax(-1))
         _note("enc.fp16x3.%s.logits.maxabs" % name, _err(logits, r["logits"]))
         _note("enc.fp16x3.%s.w.maxabs" % name, _err(w, r["w"]))
-        assert _err(logits, r["logits"]) <= TOL and _err(w, r["w"]) <= TOL and _err(elocs, r["locs"]) <= TOL
+        assert _err(logits, r["logits"]) <= TOL and _err(w, r["w"]) <= TOL and _err(elocs, r["enc_locs"]) <= TOL
         p64, p32 = [], []
         for b, lab in enumerate(labels):
             img, a, c = nets[1](styles=w[b:b + 1].repeat(lab.shape[0], 1), labels=lab, noise=None)

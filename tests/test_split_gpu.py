@@ -183,8 +183,8 @@ def test_conv_input_transform(swish):
 
 
 def test_pointwise_kernels_match_the_fp32_kernels():
-    """upsample / affine+swish / GroupNorm statistics / embedding gather on split-half == the fp32 kernels on the same values,
-    up to the split rounding of the stored result"""
+    """upsample / affine+swish / GroupNorm statistics / embedding gather on split-half against the fp32 kernels on the same
+    values: equal up to the split rounding of the stored result (2^-22) and fma contraction"""
     ops, P = _ops(), _P()
     x = _q(_rnd((3, 64, 6, 10), 51))
     xs, xf = _to_split(x), x.permute(0, 2, 3, 1).contiguous().to(DEV)
@@ -195,13 +195,14 @@ def test_pointwise_kernels_match_the_fp32_kernels():
                        ("affine", ops.affine_act(xs, sc, sh), ops.affine_act(xf, sc, sh)),
                        ("affine+swish", ops.affine_act(xs, sc, sh, swish=True), ops.affine_act(xf, sc, sh, swish=True))):
         got = ops.convert(a, torch.float32).cpu()
-        assert torch.equal(got, _q(b.cpu())), name                    # same fp32 arithmetic, then one split rounding
+        # the same fp32 arithmetic, then one split rounding (the two instantiations may contract mul+add into fma differently)
+        _check("split vs fp32 " + name, got, b.cpu(), tol=1e-6)
     g, be = (_rnd((64,), 54).abs() + 0.5).to(DEV), _rnd((64,), 55, 0.2).to(DEV)
     vw = torch.tensor([10, 7, 3], dtype=torch.int32, device=DEV)
     for v in (None, vw):
         s1, h1 = ops.groupnorm_affine(xs, g, be, 1e-6, v)
         s2, h2 = ops.groupnorm_affine(xf, g, be, 1e-6, v)
-        assert torch.equal(s1, s2) and torch.equal(h1, h2)
+        assert (s1 - s2).abs().max().item() <= 1e-6 * s2.abs().max().item() and (h1 - h2).abs().max().item() <= 1e-6
     emb = _rnd((50, 64), 56).to(DEV)
     lab = torch.tensor([[3], [49], [0]], device=DEV)
     e1 = ops.convert(ops.embed_gather(emb, lab, P.SPLIT_DTYPE, 50), torch.float32)
@@ -229,13 +230,13 @@ def test_glyph_kernels_match_the_fp32_kernels(G):
     for split in (False, True):
         o1, s1, h1 = ops.adain_crop_concat_gn(ps, fs, tab.g_img, tab.g_x1, tab.g_y1, tab.g_w, g, be, 1e-6, split=split)
         o2, s2, h2 = ops.adain_crop_concat_gn(pf, ff, tab.g_img, tab.g_x1, tab.g_y1, tab.g_w, g, be, 1e-6, split=split)
-        assert torch.equal(ops.convert(o1, torch.float32).cpu(), _q(o2.cpu()))
-        assert torch.equal(s1, s2) and torch.equal(h1, h2)
+        _check("split vs fp32 adain (split=%s)" % split, ops.convert(o1, torch.float32).cpu(), o2.cpu(), tol=1e-6)
+        assert (s1 - s2).abs().max().item() <= 1e-6 * s2.abs().max().item() and (h1 - h2).abs().max().item() <= 1e-6 * max(1.0, h2.abs().max().item())
     sc, sh = _q(_rnd((G, C, S, S), 65)), _q(_rnd((G, C, S, S), 66))
     a = ops.glyph_scatter_affine(fs, _to_split(sc), _to_split(sh), tab.g_start, tab.g_x1, tab.g_w)
     b = ops.glyph_scatter_affine(ff, sc.permute(0, 2, 3, 1).contiguous().to(DEV), sh.permute(0, 2, 3, 1).contiguous().to(DEV),
                                  tab.g_start, tab.g_x1, tab.g_w)
-    assert torch.equal(ops.convert(a, torch.float32).cpu(), _q(b.cpu()))
+    _check("split vs fp32 scatter", ops.convert(a, torch.float32).cpu(), b.cpu(), tol=1e-6)
 
 
 def test_conv3x3_rgb_split_input():
@@ -246,6 +247,6 @@ def test_conv3x3_rgb_split_input():
     wr = wt.permute(0, 2, 3, 1).contiguous().to(DEV)
     y1, y2 = ops.conv3x3_rgb(_to_split(x), wr, bias.to(DEV), ops.ACT_TANH, nhwc=True, nchw=True)
     z1, z2 = ops.conv3x3_rgb(x.permute(0, 2, 3, 1).contiguous().to(DEV), wr, bias.to(DEV), ops.ACT_TANH, nhwc=True, nchw=True)
-    assert y1.dtype == torch.float32 and torch.equal(y1, z1) and torch.equal(y2, z2)      # the same fp32 kernel after staging
+    assert y1.dtype == torch.float32 and (y1 - z1).abs().max().item() <= 1e-6 and (y2 - z2).abs().max().item() <= 1e-6   # the same fp32 kernel after staging
     ref = torch.tanh(F.conv2d(x.double(), wt.double(), padding=1) + bias[None, :, None, None].double())
     _check("conv3x3_rgb split", y2.cpu(), ref, tol=2e-6)
