@@ -226,7 +226,8 @@ int mnet_layernorm(const float* x, const float* gamma, const float* beta, float*
 int mnet_token_mix(const float* x, const float* ln_g, const float* ln_b, const float* wgt,
                    const float* bias, float* y, int32_t B, int32_t T, int32_t D, int32_t J, float eps,
                    void* stream);
-/* K8 softmax(q k^T * scale) v per (batch, head); qkv [B,N,3*H*64] packed (q|k|v, each '(h d)'),
+/* K8 softmax(q k^T * scale) v per (batch, head) on the matrix cores (v_mfma_f32_16x16x4_f32: exact fp32 products — the character
+ * indices downstream stay bit-exact); qkv [B,N,3*H*64] packed (q|k|v, each '(h d)'),
  * out [B,N,H*64]; N <= 64, head dim 64   (textvit_arch.py:104-112) */
 int mnet_attention(const float* qkv, float* out, int32_t B, int32_t N, int32_t H, float scale,
                    void* stream);
@@ -271,6 +272,31 @@ int mnet_conv3x3_rgb(const void* x, int32_t dtype, int32_t n, int32_t h, int32_t
  * script hands to cv2.imwrite) or uint8 (dst_u8 != 0: cv2's float→uchar conversion, round half to even) — 4x fewer bytes
  * for the device→host copy and the multi-GPU all-gather (SURVEY.md §8f NEXT-1) */
 int mnet_sr_postprocess(const void* src, int32_t src_dtype, void* dst, int32_t dst_u8, int64_t npix, int32_t c_ld, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * One-time weight packing on the device: from the checkpoint's tensors to the layouts above, without PyTorch
+ * or a BLAS on the host side.
+ * ------------------------------------------------------------------------------------------- */
+/* K18: w_oihw fp32 [cout][cin][kh][kw] (the checkpoint's layout: nn.Conv2d / ModulatedConv2d[0] / nn.Linear with kh = kw = 1)
+ *   → packed [cout_pad][kh][kw][cin_pad] in `dtype` (zero padded), every element = (w / sigma) * scale, where
+ *   sigma = u^T (W_mat v), W_mat = w viewed as [cout][cin*kh*kw] — the eval-mode old-style torch.nn.utils.spectral_norm fold the
+ *   reference recomputes on every forward (models/networks.py:14; weight_orig / weight_u / weight_v of the 33 SN convs of
+ *   TSPSRNet); sn_u == sn_v == NULL: no fold (sigma = 1).  `scale`: the layer's constant factor (ModulatedConv2d
+ *   1/sqrt(cin*k*k), networks.py:262,284; EqualLinear lr_mul/sqrt(in), :180,192).  MNET_F16X2 additionally stores hi/lo of
+ *   256 * value (cin_pad % 32 == 0).  workspace: cout + 1 doubles (only read when sn_u != NULL); sigma is summed in fp64 in a
+ *   fixed order (deterministic). */
+int mnet_pack_weights(const float* w_oihw, int32_t cout, int32_t cin, int32_t kh, int32_t kw, const float* sn_u,
+                      const float* sn_v, float scale, int32_t dtype, int32_t cout_pad, int32_t cin_pad, void* packed,
+                      double* workspace, void* stream);
+/* demodulation table of a ModulatedConv2d for activation-side modulation (input of mnet_demod):
+ *   wsq_t[i][o] = sum_{r,s} (scale * w[o][i][r][s])^2,  fp32 [cin][cout]   (networks.py:284-287) */
+int mnet_pack_wsq(const float* w_oihw, int32_t cout, int32_t cin, int32_t khw, float scale, float* wsq_t, void* stream);
+
+/* dst[r][0..ncols) = src[idx ? idx[r] : r][col0 .. col0+ncols)  (fp32; src [src_rows][ld]; idx int64 [rows] or NULL): every glyph
+ * takes its image's row of the per-style tensors (test_sr.py:183 gives all glyphs of a strip the same w), every StyledConv its
+ * column window of the one batched modulation GEMM (networks.py:141,283).  Indices are not range-checked. */
+int mnet_gather_rows(const float* src, int32_t src_rows, int32_t ld, int32_t col0, int32_t ncols, const int64_t* idx,
+                     int32_t rows, float* dst, void* stream);
 
 #ifdef __cplusplus
 }

@@ -7,7 +7,7 @@ mkdir -p "$OUT"
 HIPCC="${HIPCC:-/opt/rocm/bin/hipcc}"
 PIDS=()
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-function"
-for f in api conv_igemm conv_igemm_dma conv_strip_dma conv_skinny aux_kernels vit_kernels; do
+for f in api conv_igemm conv_igemm_dma conv_strip_dma conv_skinny aux_kernels vit_kernels pack_kernels; do
   if [ ! -f "$OUT/$f.o" ] || [ "$HERE/$f.hip" -nt "$OUT/$f.o" ] || [ "$HERE/common.h" -nt "$OUT/$f.o" ] || [ "$HERE/conv_args.h" -nt "$OUT/$f.o" ] || [ "$HERE/conv_dma_common.h" -nt "$OUT/$f.o" ] \
      || [ "$HERE/../../include/marconet_hip.h" -nt "$OUT/$f.o" ]; then
     echo "[build] hipcc $f.hip"
@@ -18,5 +18,5 @@ done
 for p in "${PIDS[@]:-}"; do        # a failed compile must fail the build (a stale object would otherwise be linked)
   if [ -n "$p" ]; then wait "$p"; fi
 done
-"$HIPCC" --offload-arch=gfx950 -shared -fPIC "$OUT"/api.o "$OUT"/conv_igemm.o "$OUT"/conv_igemm_dma.o "$OUT"/conv_strip_dma.o "$OUT"/conv_skinny.o "$OUT"/aux_kernels.o "$OUT"/vit_kernels.o -o "$OUT/libmarconet_hip.so"
+"$HIPCC" --offload-arch=gfx950 -shared -fPIC "$OUT"/api.o "$OUT"/conv_igemm.o "$OUT"/conv_igemm_dma.o "$OUT"/conv_strip_dma.o "$OUT"/conv_skinny.o "$OUT"/aux_kernels.o "$OUT"/vit_kernels.o "$OUT"/pack_kernels.o -o "$OUT/libmarconet_hip.so"
 echo "[build] $OUT/libmarconet_hip.so"

@@ -1,0 +1,130 @@
+// One-time weight packing on the device (SURVEY.md §2a K18, §8b `mnet_pack_weights`) and the small row gathers of the generator's
+// style plumbing.  Nothing here is on the per-pixel hot path; it exists so that a host in any language can go from the
+// checkpoint's tensors (fp32, OIHW, spectral-norm u / v vectors) to the layouts the conv kernels read without PyTorch or a
+// BLAS: the spectral-norm fold the reference redoes on every forward (models/networks.py:14 — W_orig / (u^T W_mat v), 211
+// addmv + 275 div launches per SR forward) happens once, here.
+#include "common.h"
+
+// ---------------------------------------------------------------------------- sigma = u^T (W_mat v), fp64 sums, fixed order
+// stage 1: one workgroup per output channel o: partial[o] = u[o] * sum_k W[o][k] v[k]
+__global__ void __launch_bounds__(256) sn_rowdot_kernel(const float* __restrict__ w, const float* __restrict__ u,
+                                                        const float* __restrict__ v, double* __restrict__ partial, int K) {
+    __shared__ double red[4];
+    const int o = blockIdx.x, t = threadIdx.x;
+    const float* row = w + (size_t)o * K;
+    double s = 0.0;
+    for (int k = t; k < K; k += 256) s += (double)row[k] * (double)v[k];
+    s = wave_sum_d(s);
+    if ((t & 63) == 0) red[t >> 6] = s;
+    __syncthreads();
+    if (t == 0) partial[o] = (double)u[o] * ((red[0] + red[1]) + (red[2] + red[3]));
+}
+// stage 2: one thread folds the rows in order → sigma (fp32, like the reference's parametrisation)
+__global__ void sn_fold_kernel(const double* __restrict__ partial, int cout, float* __restrict__ sigma) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    double s = 0.0;
+    for (int o = 0; o < cout; ++o) s += partial[o];
+    sigma[0] = (float)s;
+}
+
+// ---------------------------------------------------------------------------- OIHW fp32 → [cout_pad][kh][kw][cin_pad] T
+// one thread per packed element (coalesced writes; the strided reads of a few-MB tensor do not matter once per load)
+template <typename T>
+__global__ void __launch_bounds__(256) pack_weights_kernel(const float* __restrict__ w, T* __restrict__ dst, int cout, int cin,
+                                                           int kh, int kw, int cout_pad, int cin_pad, float scale,
+                                                           const float* __restrict__ sigma, long long total) {
+    const float sg = sigma ? sigma[0] : 1.0f;
+    for (long long id = (long long)blockIdx.x * 256 + threadIdx.x; id < total; id += (long long)gridDim.x * 256) {
+        const int i = (int)(id % cin_pad);
+        long long r = id / cin_pad;
+        const int s = (int)(r % kw); r /= kw;
+        const int rr = (int)(r % kh);
+        const int o = (int)(r / kh);
+        float v = 0.f;
+        if (o < cout && i < cin) {
+            v = w[(((size_t)o * cin + i) * kh + rr) * kw + s];
+            if (sigma) v = v / sg;                     // W_orig / sigma first (the reference's weight, an fp32 division), then the layer's constant scale
+            v *= scale;
+        }
+        st_elem<T>(dst + (id - i), i, v);              // dst + first element of this (o, r, s) row; st_elem handles the split layout
+    }
+}
+
+extern "C" int mnet_pack_weights(const float* w_oihw, int32_t cout, int32_t cin, int32_t kh, int32_t kw, const float* sn_u,
+                                 const float* sn_v, float scale, int32_t dtype, int32_t cout_pad, int32_t cin_pad, void* packed,
+                                 double* workspace, void* stream) {
+    MNET_CHECK_ARG(w_oihw && packed && cout > 0 && cin > 0 && kh > 0 && kw > 0, "pack_weights: bad args");
+    MNET_CHECK_ARG(cout_pad >= cout && cin_pad >= cin, "pack_weights: padded sizes smaller than the tensor");
+    MNET_CHECK_ARG(dtype == MNET_F32 || dtype == MNET_F16 || dtype == MNET_F16X2, "pack_weights: bad dtype");
+    MNET_CHECK_ARG((sn_u == nullptr) == (sn_v == nullptr), "pack_weights: sn_u and sn_v go together");
+    MNET_CHECK_ARG(!sn_u || workspace, "pack_weights: the spectral-norm fold needs a workspace of cout + 1 doubles");
+    MNET_CHECK_ALIGN(dtype != MNET_F16X2 || (cin_pad % 32 == 0 && aligned128(packed)), "pack_weights: split-half needs cin_pad %% 32 == 0, 128-byte aligned");
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    float* sigma = nullptr;
+    if (sn_u) {
+        sigma = reinterpret_cast<float*>(workspace + cout);
+        hipLaunchKernelGGL(sn_rowdot_kernel, dim3(cout), dim3(256), 0, st, w_oihw, sn_u, sn_v, workspace, cin * kh * kw);
+        MNET_LAUNCH_CHECK("sn_rowdot");
+        hipLaunchKernelGGL(sn_fold_kernel, dim3(1), dim3(64), 0, st, workspace, cout, sigma);
+        MNET_LAUNCH_CHECK("sn_fold");
+    }
+    const long long total = (long long)cout_pad * kh * kw * cin_pad;
+    const int blocks = (int)((total + 255) / 256 < 16384 ? (total + 255) / 256 : 16384);
+    if (dtype == MNET_F16X2) {
+        // hi / lo of MNET_SPLIT_WSCALE * W (exponent offset, undone by the conv epilogue)
+        hipLaunchKernelGGL(pack_weights_kernel<hs>, dim3(blocks), dim3(256), 0, st, w_oihw, (hs*)packed, cout, cin, kh, kw, cout_pad, cin_pad,
+                           scale * MNET_SPLIT_WSCALE, sigma, total);
+    } else if (dtype == MNET_F16) {
+        hipLaunchKernelGGL(pack_weights_kernel<f16>, dim3(blocks), dim3(256), 0, st, w_oihw, (f16*)packed, cout, cin, kh, kw, cout_pad, cin_pad, scale, sigma, total);
+    } else {
+        hipLaunchKernelGGL(pack_weights_kernel<float>, dim3(blocks), dim3(256), 0, st, w_oihw, (float*)packed, cout, cin, kh, kw, cout_pad, cin_pad, scale, sigma, total);
+    }
+    MNET_LAUNCH_CHECK("pack_weights");
+    return MNET_OK;
+}
+
+// ---------------------------------------------------------------------------- demodulation table
+// wsq_t[i][o] = scale^2 * sum_{r,s} W[o][i][r][s]^2   (ModulatedConv2d, models/networks.py:284-287, for activation-side modulation)
+__global__ void __launch_bounds__(256) pack_wsq_kernel(const float* __restrict__ w, float* __restrict__ wsq_t, int cout, int cin,
+                                                       int khw, float scale2) {
+    const int id = blockIdx.x * 256 + threadIdx.x;
+    if (id >= cout * cin) return;
+    const int o = id % cout, i = id / cout;              // consecutive threads → consecutive o: coalesced writes
+    const float* p = w + ((size_t)o * cin + i) * khw;
+    float s = 0.f;
+    for (int k = 0; k < khw; ++k) s = fmaf(p[k] * scale2, p[k], s);   // (scale*w)^2 summed; scale2 = scale^2
+    wsq_t[(size_t)i * cout + o] = s;
+}
+
+extern "C" int mnet_pack_wsq(const float* w_oihw, int32_t cout, int32_t cin, int32_t khw, float scale, float* wsq_t, void* stream) {
+    MNET_CHECK_ARG(w_oihw && wsq_t && cout > 0 && cin > 0 && khw > 0, "pack_wsq: bad args");
+    const int tot = cout * cin;
+    hipLaunchKernelGGL(pack_wsq_kernel, dim3((tot + 255) / 256), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), w_oihw, wsq_t,
+                       cout, cin, khw, scale * scale);
+    MNET_LAUNCH_CHECK("pack_wsq");
+    return MNET_OK;
+}
+
+// ---------------------------------------------------------------------------- row gather with a column window
+// dst[r][0..ncols) = src[idx ? idx[r] : r][col0 .. col0 + ncols)   (fp32; src row stride ld).  The generator computes the style
+// MLP / modulations / demodulation once per distinct style (one per image) and hands every glyph its image's row, and every
+// StyledConv its own column window of the one batched modulation GEMM (models/networks.py:141,283).
+__global__ void __launch_bounds__(256) gather_rows_kernel(const float* __restrict__ src, int ld, int col0, int ncols,
+                                                          const int64_t* __restrict__ idx, float* __restrict__ dst, long long total) {
+    for (long long id = (long long)blockIdx.x * 256 + threadIdx.x; id < total; id += (long long)gridDim.x * 256) {
+        const int c = (int)(id % ncols);
+        const long long r = id / ncols;
+        const long long sr = idx ? idx[r] : r;
+        dst[id] = src[(size_t)sr * ld + col0 + c];
+    }
+}
+
+extern "C" int mnet_gather_rows(const float* src, int32_t src_rows, int32_t ld, int32_t col0, int32_t ncols, const int64_t* idx,
+                                int32_t rows, float* dst, void* stream) {
+    MNET_CHECK_ARG(src && dst && src_rows > 0 && rows > 0 && ncols > 0 && col0 >= 0 && col0 + ncols <= ld, "gather_rows: bad args");
+    const long long total = (long long)rows * ncols;
+    const int blocks = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
+    hipLaunchKernelGGL(gather_rows_kernel, dim3(blocks), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), src, ld, col0, ncols, idx, dst, total);
+    MNET_LAUNCH_CHECK("gather_rows");
+    return MNET_OK;
+}

@@ -82,68 +82,94 @@ extern "C" int mnet_token_mix(const float* x, const float* ln_g, const float* ln
     return MNET_OK;
 }
 
-// ---------------------------------------------------------------------------- attention, N<=64, d=64
-// one workgroup per (batch, head): Q,K,V rows in LDS (row stride 65 floats → conflict-free column walks),
-// thread (i = t/4, quarter = t%4) owns 16 score columns of query row i; row max / sum reduce over the
-// 4 neighbouring lanes with xor-shuffles; P goes back through LDS for the P·V product.
+// ---------------------------------------------------------------------------- attention, N<=64, d=64, on the matrix cores
+// softmax(q k^T * scale) v per (batch, head) with v_mfma_f32_16x16x4_f32 (exact fp32 products, fp32 accumulate: the character
+// indices downstream must stay bit-exact, so no reduced precision here).  One workgroup per (batch, head); Q, K, V rows in LDS
+// with a row stride of 68 floats (the MFMA operand reads — 16 rows x 4 consecutive k — then hit 64 distinct banks).
+// Wave w owns query rows 16w..16w+15:
+//   S = Q K^T : A = Q[row l16][k = 4 ks + g], B = K[key l16][k = 4 ks + g]  → acc[kb][q] = S[row 4g+q][key 16 kb + l16]
+//   softmax   : a query row lives in the 16 lanes of one g-group x 4 key blocks → in-thread + 4 xor-shuffles (1,2,4,8)
+//   O = P V   : P goes back through the wave's own Q rows (D layout → A layout), B = V[key 4 ks + g][col 16 cb + l16]
 __global__ void __launch_bounds__(256) attention_kernel(const float* __restrict__ qkv, float* __restrict__ out,
                                                         int N, int H, float scale) {
-    __shared__ float sq[64][65], sk[64][65], sv[64][65];
-    float (*sp)[65] = sq;   // P overwrites Q once every thread is done with Q (barrier below)
+    constexpr int LD = 68;
+    __shared__ float sq[64 * LD], sk[64 * LD], sv[64 * LD];
     const int b = blockIdx.x / H, h = blockIdx.x % H, t = threadIdx.x;
+    const int lane = t & 63, wave = t >> 6, l16 = lane & 15, g = lane >> 4;
     const int HD = H * 64;
     const float* base = qkv + (size_t)b * N * 3 * HD + h * 64;
-    for (int e = t; e < N * 64; e += 256) {
+    for (int e = t; e < 64 * 64; e += 256) {
         const int r = e >> 6, c = e & 63;
-        const float* row = base + (size_t)r * 3 * HD;
-        sq[r][c] = row[c]; sk[r][c] = row[HD + c]; sv[r][c] = row[2 * HD + c];
+        float q = 0.f, k = 0.f, v = 0.f;
+        if (r < N) { const float* row = base + (size_t)r * 3 * HD; q = row[c]; k = row[HD + c]; v = row[2 * HD + c]; }
+        sq[r * LD + c] = q; sk[r * LD + c] = k; sv[r * LD + c] = v;
     }
     __syncthreads();
-    const int i = t >> 2, qd = t & 3;
-    float s[16];
-    float mx = -INFINITY;
-    if (i < N) {
+    const int nb = (N + 15) >> 4;                        // 16-row blocks of queries == of keys
+    const bool live = wave < nb;                         // wave-uniform
+    f32x4 s[4];
+    if (live) {
 #pragma unroll
-        for (int jj = 0; jj < 16; ++jj) {
-            const int j = qd * 16 + jj;
-            float acc = 0.f;
-            if (j < N) {
-                for (int c = 0; c < 64; ++c) acc = fmaf(sq[i][c], sk[j][c], acc);
-                acc *= scale;
-                mx = fmaxf(mx, acc);
+        for (int kb = 0; kb < 4; ++kb) s[kb] = f32x4{0.f, 0.f, 0.f, 0.f};
+        const float* qa = sq + (wave * 16 + l16) * LD + g;
+        const float* ka = sk + l16 * LD + g;
+#pragma unroll
+        for (int ks = 0; ks < 16; ++ks) {
+            const float a = qa[4 * ks];
+#pragma unroll
+            for (int kb = 0; kb < 4; ++kb)
+                if (kb < nb) s[kb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, ka[kb * 16 * LD + 4 * ks], s[kb], 0, 0, 0);
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            float mx = -INFINITY;
+#pragma unroll
+            for (int kb = 0; kb < 4; ++kb) {
+                const bool ok = kb * 16 + l16 < N;
+                s[kb][q] = ok ? s[kb][q] * scale : -INFINITY;
+                mx = fmaxf(mx, s[kb][q]);
             }
-            s[jj] = acc;
-        }
-    }
-    mx = fmaxf(mx, __shfl_xor(mx, 1, 64));
-    mx = fmaxf(mx, __shfl_xor(mx, 2, 64));
-    float sum = 0.f;
-    if (i < N) {
 #pragma unroll
-        for (int jj = 0; jj < 16; ++jj) {
-            const int j = qd * 16 + jj;
-            const float e = j < N ? expf(s[jj] - mx) : 0.f;
-            s[jj] = e; sum += e;
+            for (int o = 1; o < 16; o <<= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+            float sum = 0.f;
+#pragma unroll
+            for (int kb = 0; kb < 4; ++kb) {
+                const float e = kb * 16 + l16 < N ? expf(s[kb][q] - mx) : 0.f;
+                s[kb][q] = e; sum += e;
+            }
+#pragma unroll
+            for (int o = 1; o < 16; o <<= 1) sum += __shfl_xor(sum, o, 64);
+            const float inv = 1.f / sum;
+#pragma unroll
+            for (int kb = 0; kb < 4; ++kb) s[kb][q] *= inv;
         }
     }
-    sum += __shfl_xor(sum, 1, 64);
-    sum += __shfl_xor(sum, 2, 64);
+    __syncthreads();                                     // every wave is done reading Q (only its own rows, but keep it simple)
+    if (live) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int kb = 0; kb < 4; ++kb) sq[(wave * 16 + 4 * g + q) * LD + kb * 16 + l16] = s[kb][q];
+    }
     __syncthreads();
-    if (i < N) {
-        const float inv = 1.f / sum;
+    if (!live) return;
+    f32x4 o[4];
 #pragma unroll
-        for (int jj = 0; jj < 16; ++jj) sp[i][qd * 16 + jj] = s[jj] * inv;
+    for (int cb = 0; cb < 4; ++cb) o[cb] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const float* pa = sq + (wave * 16 + l16) * LD + g;
+    const float* va = sv + g * LD + l16;
+    for (int ks = 0; ks < nb * 4; ++ks) {                // keys beyond N carry P == 0 and V == 0
+        const float a = pa[4 * ks];
+#pragma unroll
+        for (int cb = 0; cb < 4; ++cb) o[cb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, va[4 * ks * LD + cb * 16], o[cb], 0, 0, 0);
     }
-    __syncthreads();
-    if (i < N) {
-        float* o = out + ((size_t)b * N + i) * HD + h * 64 + qd * 16;
 #pragma unroll
-        for (int cc = 0; cc < 16; ++cc) {
-            const int c = qd * 16 + cc;
-            float acc = 0.f;
-            for (int j = 0; j < N; ++j) acc = fmaf(sp[i][j], sv[j][c], acc);
-            o[cc] = acc;
-        }
+    for (int q = 0; q < 4; ++q) {
+        const int row = wave * 16 + 4 * g + q;
+        if (row >= N) continue;
+        float* op = out + ((size_t)b * N + row) * HD + h * 64 + l16;
+#pragma unroll
+        for (int cb = 0; cb < 4; ++cb) op[cb * 16] = o[cb][q];
     }
 }
 

@@ -16,8 +16,8 @@ import torch.nn as nn
 
 from . import ops
 from .glyphs import GlyphTables
-from .packing import (PRECISIONS, SPLIT_DTYPE, PackCache, default_precision, equal_linear_scale, pack_conv_weight, pack_vec,
-                      rgb_pad, sn_fold, torch_dtype)
+from .packing import (PRECISIONS, SPLIT_DTYPE, PackCache, default_precision, equal_linear_scale, pack_conv_weight,
+                      pack_linear_weight, pack_vec, pack_wsq, rgb_pad, torch_dtype)
 from .resnet import resnet45stride as resnet45
 from .textvit_arch import TextViT as TextEncoder
 
@@ -162,23 +162,22 @@ class TextGenerator(nn.Module):
         pk["mlp"] = []
         for i in range(1, self.n_mlp + 1):
             el = self.style_mlp[i]
-            pk["mlp"].append((f(el.weight.detach() * el.scale), f(el.bias.detach() * el.lr_mul)))   # networks.py:192-195
+            pk["mlp"].append((pack_linear_weight(el.weight, el.scale), f(el.bias.detach() * el.lr_mul)))   # networks.py:192-195
         pk["emb"] = f(self.input_text.TextEmbeddings.detach().reshape(self.class_num, -1))
 
         def styled(sc):
             mc = sc.conv
-            w = mc.scale * mc.weight.detach()[0]                                   # [Cout,Cin,3,3], networks.py:284
+            w0 = mc.weight.detach()[0]                                             # [Cout,Cin,3,3]; scale folded in (networks.py:284)
             return dict(cin=mc.in_channel, cout=mc.out_channel, up=mc.upsample,
-                        w=pack_conv_weight(w, dtype),
-                        wsq_t=f((w * w).sum(dim=(2, 3)).t()),                      # [Cin,Cout] for the demod table
-                        mod_w=f(mc.modulation.weight.detach() * mc.modulation.scale), mod_b=f(mc.modulation.bias),
+                        w=pack_conv_weight(w0, dtype, scale=mc.scale),
+                        wsq_t=pack_wsq(w0, mc.scale),                              # [Cin,Cout] for the demod table
+                        mod_w=pack_linear_weight(mc.modulation.weight, mc.modulation.scale), mod_b=f(mc.modulation.bias),
                         bias=f(sc.bias.detach().reshape(-1) + sc.activate.bias.detach()))   # :244 then :245
 
         def torgb(tr):
             mc = tr.conv
-            w = mc.scale * mc.weight.detach()[0]                                   # [3,Cin,1,1]
-            return dict(cin=mc.in_channel, w=pack_conv_weight(w, dtype, cout_mult=rgb_pad(dtype)),
-                        mod_w=f(mc.modulation.weight.detach() * mc.modulation.scale), mod_b=f(mc.modulation.bias),
+            return dict(cin=mc.in_channel, w=pack_conv_weight(mc.weight.detach()[0], dtype, cout_mult=rgb_pad(dtype), scale=mc.scale),   # [3,Cin,1,1]
+                        mod_w=pack_linear_weight(mc.modulation.weight, mc.modulation.scale), mod_b=f(mc.modulation.bias),
                         bias=pack_vec(tr.bias, rgb_pad(dtype)))
 
         pk["conv1"] = styled(self.conv1)
@@ -198,35 +197,40 @@ class TextGenerator(nn.Module):
         return pk
 
     # ------------------------------------------------------------------ forward pieces
-    def _style(self, L, S):
-        """this layer's slice of the batched modulation EqualLinear (:283) and its demodulation table
-        rsqrt(Σ (scale·W·s)² + 1e-8) (:286)"""
-        s = S[:, L["mod_off"]:L["mod_off"] + L["cin"]].contiguous()
-        if getattr(self, "_gidx", None) is not None:      # demodulation once per distinct style, gathered per glyph
-            su = self._lat_u[:, L["mod_off"]:L["mod_off"] + L["cin"]].contiguous()
-            return s, ops.demod(su, L["wsq_t"]).index_select(0, self._gidx)
-        return s, ops.demod(s, L["wsq_t"])
+    def _mod(self, L):
+        """this layer's column window of the batched modulation EqualLinear (:283), one row per glyph (mnet_gather_rows: the
+        window and — with distinct styles — the glyph → style row gather in one small launch)"""
+        return ops.gather_rows(self._S, L["mod_off"], L["cin"], self._gidx)
+
+    def _style(self, L):
+        """→ (modulation rows per glyph, demodulation table rsqrt(Σ (scale·W·s)² + 1e-8) per glyph (:286))"""
+        s = self._mod(L)
+        if self._gidx is None:
+            return s, ops.demod(s, L["wsq_t"])
+        su = ops.gather_rows(self._S, L["mod_off"], L["cin"])       # demodulation once per distinct style, gathered per glyph
+        return s, ops.gather_rows(ops.demod(su, L["wsq_t"]), idx=self._gidx)
 
     @staticmethod
-    def _styled(L, x, s, d, premodulated, post=None):
+    def _styled(L, x, s, d, premodulated, post=None, out=None):
         """StyledConv with activation-side modulation.  ``premodulated``: x already carries ·s (applied once per
         element by the producer: the fused upsample or the previous conv's post_scale) — otherwise the conv
         prologue applies it.  ``post``: the NEXT StyledConv's style, multiplied into this conv's output."""
         return ops.conv2d(x, L["w"], L["cout"], 3, 3, (1, 1), (1, 1), in_scale=None if premodulated else s,
-                          out_scale=d, bias=L["bias"], act=ops.ACT_LRELU_SQRT2, post_scale=post)
+                          out_scale=d, bias=L["bias"], act=ops.ACT_LRELU_SQRT2, post_scale=post, out=out)
 
-    @staticmethod
-    def _to_rgb(L, x, S, skip):
-        s = S[:, L["mod_off"]:L["mod_off"] + L["cin"]].contiguous()
+    def _to_rgb(self, L, x, skip):
+        s = self._mod(L)
         if skip is not None:
             skip = ops.upsample2x(skip)                                        # :318-319
         return ops.conv2d(x, L["w"], L["w"].shape[0], in_scale=s, bias=L["bias"], residual=skip, act=ops.ACT_TANH)
 
-    def forward_nhwc(self, styles, labels, need_image=True, style_index=None):
+    def forward_nhwc(self, styles, labels, need_image=True, style_index=None, p64_out=None, p32_out=None):
         """→ (image NHWC [N,128,128c,8], prior64 NHWC [N,64,64c,256], prior32 NHWC [N,32,32c,512]).
         ``style_index`` (int64 [N], optional): ``styles`` then holds only the DISTINCT style vectors (one per image in
         test_sr.py:183, where every glyph of an image gets the same w) and glyph i uses styles[style_index[i]] — the style
         MLP, the 17 modulations and the 11 demodulation tables run once per distinct style and are gathered per glyph.
+        ``p64_out`` / ``p32_out``: preallocated NHWC [N,64,64,256] / [N,32,32,512] views the two prior levels are written into by
+        the producing conv itself (the batched driver hands slices of its all-glyph buffers: no concatenation pass afterwards).
         ``need_image=False`` (opt-in, batched SR driver only) stops after the 64-px level: the 128-px level feeds nothing
         but the visualisation image (models/networks.py:148-164; 35 % of the generator's FLOPs) and ``image`` is None."""
         pk = self._cache.get(self, self.precision, self._build)
@@ -235,31 +239,27 @@ class TextGenerator(nn.Module):
         for w, b in pk["mlp"]:
             lat = ops.linear(lat, w, self.style_dim, bias=b, act=ops.ACT_LRELU_SQRT2)
         x = ops.embed_gather(pk["emb"], labels, dtype, self.class_num)         # SelectText (:205-215)
-        lat = ops.linear(lat, pk["mod_all_w"], pk["mod_total"], bias=pk["mod_all_b"])    # every layer's modulation at once
-        if style_index is not None:
-            # per-style rows → per-glyph rows (pure gathers).  _style() slices `lat`; the demod tables are computed on the
-            # distinct rows and gathered through `self._gidx`
-            self._gidx, self._lat_u = style_index, lat
-            lat = lat.index_select(0, style_index)
-        else:
-            self._gidx = self._lat_u = None
-        s, d = self._style(pk["conv1"], lat)
+        # every layer's modulation at once: [styles, Σ cin]; _mod() / _style() take per-layer column windows of it, per glyph
+        self._S = ops.linear(lat, pk["mod_all_w"], pk["mod_total"], bias=pk["mod_all_b"])
+        self._gidx = style_index
+        s, d = self._style(pk["conv1"])
         x = self._styled(pk["conv1"], x, s, d, premodulated=False)
-        skip = self._to_rgb(pk["rgb1"], x, lat, None) if need_image else None
+        skip = self._to_rgb(pk["rgb1"], x, None) if need_image else None
         p64 = p32 = None
         for lvl in range(len(pk["rgbs"])):
             if not need_image and p64 is not None and p32 is not None:
                 return None, p64, p32
             La, Lb = pk["convs"][2 * lvl], pk["convs"][2 * lvl + 1]
-            sa, da = self._style(La, lat)
-            sb, db = self._style(Lb, lat)
+            sa, da = self._style(La)
+            sb, db = self._style(Lb)
             xu = ops.upsample2x(x, scale=sa)                                   # bilinear ×2 (:293) with ·s_a fused
             xa = self._styled(La, xu, sa, da, premodulated=True, post=sb)      # emits x_a·s_b (x_a has no other reader)
             del xu
-            x = self._styled(Lb, xa, sb, db, premodulated=True)
+            wx = xa.shape[2]                                                   # this level's width (absolute, see below)
+            x = self._styled(Lb, xa, sb, db, premodulated=True, out=p64_out if wx == 64 else (p32_out if wx == 32 else None))
             del xa
             if need_image:
-                skip = self._to_rgb(pk["rgbs"][lvl], x, lat, skip)
+                skip = self._to_rgb(pk["rgbs"][lvl], x, skip)
             if x.shape[2] == 64:              # ABSOLUTE width, like the reference (:155,158): with c characters per
                 p64 = x                       # sample the map is 4c·2^k wide, so c = 2 hands out the 32x64 / 16x32 levels
             if x.shape[2] == 32:
@@ -369,7 +369,7 @@ class TSPSRNet(nn.Module, _Precision):
         pk = {}
 
         def sn(name, m, cout_mult=4):
-            w = pack_conv_weight(sn_fold(m.weight_orig, m.weight_u, m.weight_v), dtype, cout_mult=cout_mult)
+            w = pack_conv_weight(m.weight_orig.detach(), dtype, cout_mult=cout_mult, sn=(m.weight_u, m.weight_v))
             cp = w.shape[0]                                    # padded cout (whole 32-channel blocks in the split-half mode)
             pk[name] = dict(w=w, b=pack_vec(m.bias, cp), cout=cp, stride=(m.stride, m.stride))
 
@@ -393,7 +393,7 @@ class TSPSRNet(nn.Module, _Precision):
         res("conv_final.5", self.conv_final[5]); sn("conv_final.6", self.conv_final[6], cout_mult=rgb_pad(dtype))
         m6 = self.conv_final[6]                       # the same layer for the dedicated 64 → 3 kernel: [3][3][3][64], bias [3]
         rgb_dt = torch.float32 if dtype == SPLIT_DTYPE else dtype          # (the split-half mode runs this 64 → 3 layer in fp32)
-        pk["conv_final.6.rgb"] = (sn_fold(m6.weight_orig, m6.weight_u, m6.weight_v).permute(0, 2, 3, 1).contiguous().to(rgb_dt),
+        pk["conv_final.6.rgb"] = (pack_conv_weight(m6.weight_orig.detach(), rgb_dt, cin_mult=1, cout_mult=1, sn=(m6.weight_u, m6.weight_v)),
                                   m6.bias.detach().float().contiguous())
         res("conv_32_fuse.0", self.conv_32_fuse[0]); res("conv_64_fuse.0", self.conv_64_fuse[0])
         return pk

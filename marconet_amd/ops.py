@@ -17,6 +17,7 @@ from .packing import SPLIT_DTYPE
 __all__ = ["conv2d", "linear", "nchw_to_nhwc", "nhwc_to_nchw", "upsample2x", "affine_act", "groupnorm_affine",
            "adain_crop_concat", "adain_crop_concat_gn", "glyph_scatter_affine", "layernorm", "token_mix", "attention", "pixelnorm",
            "embed_gather", "demod", "argmax_rows", "convert", "fused_bias_act", "sr_postprocess", "conv3x3_rgb", "stats",
+           "pack_weights", "pack_wsq", "gather_rows",
            "ACT_NONE", "ACT_RELU", "ACT_LRELU", "ACT_LRELU_SQRT2", "ACT_TANH", "ACT_GELU", "ACT_SIGMOID"]
 
 
@@ -100,6 +101,8 @@ def conv2d(x0, wgt, cout, kh=1, kw=1, stride=(1, 1), pad=(0, 0), x1=None, in_sca
     wo = (w + 2 * pad[1] - kw) // stride[1] + 1
     if out is None:
         out = torch.empty((n, ho, wo, cout), dtype=x0.dtype, device=x0.device)
+    elif tuple(out.shape) != (n, ho, wo, cout) or out.dtype != x0.dtype:
+        raise RuntimeError("conv2d: out is %s %s, expected %s %s" % (tuple(out.shape), out.dtype, (n, ho, wo, cout), x0.dtype))
     d = ConvDesc()
     d.dtype = _dt(x0)
     d.x0, d.c0 = x0.data_ptr(), c0
@@ -374,6 +377,54 @@ def sr_postprocess(y_nhwc, u8=True):
     _lib.check(lib.mnet_sr_postprocess(_p(y_nhwc), _dt(y_nhwc), _p(out), 1 if u8 else 0, b * h * w, c_ld, _stream()),
                "mnet_sr_postprocess")
     return out
+
+
+def pack_weights(w, dtype, cout_pad=None, cin_pad=None, scale=1.0, sn_u=None, sn_v=None):
+    """mnet_pack_weights: w fp32 [cout,cin,kh,kw] (or [out,in] for a Linear) on the device → [cout_pad,kh,kw,cin_pad] in ``dtype``,
+    every element (w / sigma) * scale with sigma = uᵀ(W_mat v) when the spectral-norm vectors are given (models/networks.py:14)."""
+    lib = _lib.load()
+    w = w.detach()
+    if w.dim() == 2:
+        w = w.reshape(w.shape[0], w.shape[1], 1, 1)
+    w = w.contiguous()
+    if w.dtype != torch.float32:
+        w = w.float()
+    if sn_u is not None:
+        sn_u, sn_v = sn_u.detach().float().contiguous(), sn_v.detach().float().contiguous()
+    _need_cuda(w, sn_u, sn_v)
+    cout, cin, kh, kw = w.shape
+    cout_pad, cin_pad = cout_pad or cout, cin_pad or cin
+    out = torch.empty((cout_pad, kh, kw, cin_pad), dtype=dtype, device=w.device)
+    ws = torch.empty((cout + 1,), dtype=torch.float64, device=w.device) if sn_u is not None else None
+    _lib.check(lib.mnet_pack_weights(_p(w), cout, cin, kh, kw, _p(sn_u), _p(sn_v), float(scale), _dt(out), cout_pad, cin_pad, _p(out),
+                                     _p(ws), _stream()), "mnet_pack_weights")
+    return out
+
+
+def pack_wsq(w, scale):
+    """mnet_pack_wsq: demodulation table [cin,cout] of a ModulatedConv2d weight [cout,cin,kh,kw] (fp32, device)"""
+    lib = _lib.load()
+    w = w.detach().float().contiguous()
+    _need_cuda(w)
+    cout, cin, kh, kw = w.shape
+    out = torch.empty((cin, cout), dtype=torch.float32, device=w.device)
+    _lib.check(lib.mnet_pack_wsq(_p(w), cout, cin, kh * kw, float(scale), _p(out), _stream()), "mnet_pack_wsq")
+    return out
+
+
+def gather_rows(src, col0=0, ncols=None, idx=None):
+    """dst[r, :] = src[idx[r] (or r), col0:col0+ncols] — fp32 [rows, ncols] contiguous (mnet_gather_rows)"""
+    lib = _lib.load()
+    _need_cuda(src, idx)
+    if src.dtype != torch.float32 or src.dim() != 2 or (idx is not None and idx.dtype != torch.int64):
+        raise TypeError("gather_rows: fp32 [rows, ld] source and int64 indices expected")
+    ld = src.shape[1]
+    ncols = ld - col0 if ncols is None else ncols
+    rows = src.shape[0] if idx is None else idx.shape[0]
+    dst = torch.empty((rows, ncols), dtype=torch.float32, device=src.device)
+    if rows:
+        _lib.check(lib.mnet_gather_rows(_p(src), src.shape[0], ld, col0, ncols, _p(idx), rows, _p(dst), _stream()), "mnet_gather_rows")
+    return dst
 
 
 def conv3x3_rgb(x, wgt, bias, act=ACT_TANH, nhwc=True, nchw=False):

@@ -70,12 +70,24 @@ def _round_up(v, m):
     return (v + m - 1) // m * m
 
 
-def pack_conv_weight(w, dtype, cin_mult=8, cout_mult=4):
-    """w [O,I,KH,KW] fp32 → contiguous [O_pad,KH,KW,I_pad] in ``dtype`` (zero padded)."""
+def pack_conv_weight(w, dtype, cin_mult=8, cout_mult=4, scale=1.0, sn=None):
+    """w [O,I,KH,KW] fp32 → contiguous [O_pad,KH,KW,I_pad] in ``dtype`` (zero padded), every element (w / sigma) * scale.
+    ``sn`` = (weight_u, weight_v): eval-mode old-style spectral norm, sigma = uᵀ(W_mat v) (models/networks.py:14).
+    Parameters on a HIP device are packed by the library itself (mnet_pack_weights: no PyTorch arithmetic, no BLAS in the
+    product process); host tensors (offline tooling, the CPU tests) take the equivalent torch path below."""
     o, i, kh, kw = w.shape
     if dtype == SPLIT_DTYPE:            # whole 32-channel blocks on both sides
         cin_mult, cout_mult = max(cin_mult, 32), max(cout_mult, 32)
     op, ip = _round_up(o, cout_mult), _round_up(i, cin_mult)
+    if w.is_cuda:
+        from . import ops
+        with ops.on_device(w):
+            return ops.pack_weights(w, dtype, op, ip, scale, None if sn is None else sn[0], None if sn is None else sn[1])
+    w = w.detach().float()
+    if sn is not None:
+        w = sn_fold(w, sn[0], sn[1])
+    if scale != 1.0:
+        w = w * scale
     if op != o or ip != i:
         wp = torch.zeros((op, ip, kh, kw), dtype=w.dtype, device=w.device)
         wp[:o, :i] = w
@@ -83,6 +95,25 @@ def pack_conv_weight(w, dtype, cin_mult=8, cout_mult=4):
     if dtype == SPLIT_DTYPE:
         return split_halves(w.permute(0, 2, 3, 1).contiguous() * SPLIT_WSCALE)
     return w.permute(0, 2, 3, 1).contiguous().to(dtype)
+
+
+def pack_linear_weight(w, scale=1.0):
+    """nn.Linear / EqualLinear weight [out,in] → fp32 contiguous, times the layer's constant scale (networks.py:180,192)"""
+    if w.is_cuda:
+        from . import ops
+        with ops.on_device(w):
+            return ops.pack_weights(w, torch.float32, scale=scale).reshape(w.shape[0], w.shape[1])
+    return (w.detach().float() * scale).contiguous()
+
+
+def pack_wsq(w, scale):
+    """demodulation table [cin,cout] = Σ_k (scale·W[o,i,k])² of a ModulatedConv2d weight [cout,cin,kh,kw] (networks.py:284-287)"""
+    if w.is_cuda:
+        from . import ops
+        with ops.on_device(w):
+            return ops.pack_wsq(w, scale)
+    ws = w.detach().float() * scale
+    return (ws * ws).sum(dim=(2, 3)).t().contiguous()
 
 
 def pack_vec(b, n_pad=None):

@@ -81,20 +81,19 @@ class MarconetPipeline:
         tg.precision = self.precision
         if sum(counts):
             # w0.repeat(n,1) per image (test_sr.py:183): the generator gets the B distinct styles + the glyph→image index
-            p64s, p32s = [], []
-            for s in range(0, lab.shape[0], self.glyph_chunk):        # bounded working set for huge batches
+            # the generator runs in chunks of glyphs (bounded working set for huge batches) and writes its two prior levels
+            # straight into the all-glyph buffers TSPSRNet reads (no concatenation pass: 34 GB of copies per step at batch 256)
+            G, gdt = lab.shape[0], torch_dtype(tg.precision)
+            p64 = torch.empty((G, 64, 64, 256), dtype=gdt, device=lq.device)
+            p32 = torch.empty((G, 32, 32, 512), dtype=gdt, device=lq.device)
+            for s in range(0, G, self.glyph_chunk):
+                e = min(G, s + self.glyph_chunk)
                 if _NO_STYLE_DEDUPE:
-                    _, a, c = tg.forward_nhwc(w.index_select(0, img_of[s:s + self.glyph_chunk]).contiguous(),
-                                              lab[s:s + self.glyph_chunk].contiguous(), need_image=self.need_prior_image)
-                    p64s.append(a)
-                    p32s.append(c)
+                    tg.forward_nhwc(w.index_select(0, img_of[s:e]).contiguous(), lab[s:e].contiguous(),
+                                    need_image=self.need_prior_image, p64_out=p64[s:e], p32_out=p32[s:e])
                     continue
-                _, a, c = tg.forward_nhwc(w, lab[s:s + self.glyph_chunk].contiguous(), need_image=self.need_prior_image,
-                                          style_index=img_of[s:s + self.glyph_chunk].contiguous())
-                p64s.append(a)
-                p32s.append(c)
-            p64 = p64s[0] if len(p64s) == 1 else torch.cat(p64s)
-            p32 = p32s[0] if len(p32s) == 1 else torch.cat(p32s)
+                tg.forward_nhwc(w, lab[s:e].contiguous(), need_image=self.need_prior_image, style_index=img_of[s:e].contiguous(),
+                                p64_out=p64[s:e], p32_out=p32[s:e])
             sr_dtype = torch_dtype(self.sr.precision)                 # the three nets may run in different precision modes
             p64, p32 = ops.convert(p64, sr_dtype), ops.convert(p32, sr_dtype)
         else:

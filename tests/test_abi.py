@@ -112,6 +112,14 @@ def test_argument_validation_without_device():
     assert lib.mnet_adain_crop_concat_split(16, 16, 16, 1, 1, 32, 256, 512, 16, 16, 16, 16, None, None, 1e-6, None, None, None, 16, 16, None) == -1
     assert lib.mnet_adain_crop_concat_split(16, 16, 16, 1, 1, 32, 256, 512, 16, 16, 16, 16, 16, None, 1e-6, None, None, 16, 16, 16, None) == -1
     assert b"go together" in lib.mnet_last_error()
+    # round-2 entry points
+    assert lib.mnet_pack_weights(16, 8, 8, 3, 3, 16, None, 1.0, 1, 8, 8, 16, None, None) == -1 and b"go together" in lib.mnet_last_error()
+    assert lib.mnet_pack_weights(16, 8, 8, 3, 3, 16, 16, 1.0, 1, 8, 8, 16, None, None) == -1 and b"workspace" in lib.mnet_last_error()
+    assert lib.mnet_pack_weights(16, 8, 8, 3, 3, None, None, 1.0, 2, 8, 8, 128, None, None) == -2            # split-half: cin_pad % 32
+    assert lib.mnet_pack_weights(16, 8, 8, 3, 3, None, None, 1.0, 1, 4, 8, 128, None, None) == -1            # cout_pad < cout
+    assert lib.mnet_pack_wsq(None, 8, 8, 9, 1.0, 16, None) == -1
+    assert lib.mnet_gather_rows(16, 4, 8, 6, 4, None, 4, 16, None) == -1                                       # window beyond ld
+    assert lib.mnet_convert(128, 0, 256, 2, 24, None) == -2 and b"split-half" in lib.mnet_last_error()        # count % 32
 
 
 def test_ops_refuse_cpu_tensors():

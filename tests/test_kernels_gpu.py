@@ -290,7 +290,7 @@ def test_layernorm_tokenmix_attention():
         ref = F.linear(F.layer_norm(xt.permute(0, 2, 1), (64,), g64, b64, 1e-5), W, bb).permute(0, 2, 1)
         y = ops.token_mix(xt.to(DEV), g64.to(DEV), b64.to(DEV), W.to(DEV), bb.to(DEV))
         _check("token_mix J=%d" % J, y.cpu(), ref, torch.float32)
-    for N in (64, 16):
+    for N in (64, 16, 37, 5):          # 64 / 16: the TextViT's token counts; 37 / 5: partial last block (masked keys, skipped rows)
         B, H = 3, 8
         qkv = _rnd((B, N, 3 * 512), 38)
         q, k, v = [t.reshape(B, N, H, 64).permute(0, 2, 1, 3) for t in qkv.chunk(3, dim=-1)]
@@ -627,3 +627,43 @@ def test_patchify_conv_splitk(case):
     _check("patchify split-K %s" % (case,), _nchw(y_s), F.gelu(ref).float(), torch.float32)
     with pytest.raises(RuntimeError):
         ops.conv2d(x0, _pack_w(wt, torch.float32), cout, k, k, (k, k), (0, 0), splitk=ksplit * 3 + 1, **kw)
+
+
+@pytest.mark.parametrize("dtype_name", ["fp32", "fp16", "fp16x3"])
+@pytest.mark.parametrize("sn", [False, True])
+def test_pack_weights_on_device_matches_host_packing(dtype_name, sn):
+    """mnet_pack_weights (spectral-norm fold + scale + OIHW → [O][KH][KW][I] repack + padding, in the library) against the torch
+    host path of packing.pack_conv_weight on the same tensors"""
+    from marconet_amd import packing as P
+    ops = _ops()
+    dtype = P.torch_dtype(dtype_name)
+    w = _rnd((70, 40, 3, 3), 201, 0.05)
+    u, v = _rnd((70,), 202), _rnd((360,), 203)
+    u, v = u / u.norm(), v / v.norm()
+    snv = (u, v) if sn else None
+    host = P.pack_conv_weight(w, dtype, scale=0.37, sn=snv)
+    dev = P.pack_conv_weight(w.to(DEV), dtype, scale=0.37, sn=None if not sn else (u.to(DEV), v.to(DEV)))
+    assert dev.is_cuda and dev.shape == host.shape and dev.dtype == host.dtype
+    if dtype == P.SPLIT_DTYPE:
+        a, b = P.unsplit_halves(dev.cpu()), P.unsplit_halves(host)
+    else:
+        a, b = dev.float().cpu(), host.float()
+    # sigma: fp64 sums on the device vs torch's fp32 mv/dot on the host → 1e-6 relative; plus one rounding of the storage type
+    tol = {"fp32": 3e-6, "fp16": 1.5e-3, "fp16x3": 3e-6}[dtype_name]
+    assert (a - b).abs().max().item() <= tol * b.abs().max().item()
+    assert float(a[70:].abs().max()) == 0.0 and float(a[:, :, :, 40:].abs().max()) == 0.0           # zero padding
+
+
+def test_pack_wsq_linear_and_gather_rows():
+    from marconet_amd import packing as P
+    ops = _ops()
+    w = _rnd((48, 24, 3, 3), 211, 0.1)
+    a, b = P.pack_wsq(w.to(DEV), 0.25).cpu(), P.pack_wsq(w, 0.25)
+    assert a.shape == (24, 48) and (a - b).abs().max().item() <= 2e-6 * b.abs().max().item()
+    lw = _rnd((33, 17), 212)
+    assert torch.equal(P.pack_linear_weight(lw.to(DEV), 0.5).cpu(), P.pack_linear_weight(lw, 0.5))
+    src = _rnd((9, 40), 213)
+    idx = torch.tensor([8, 0, 0, 3, 7, 7, 1], dtype=torch.int64)
+    assert torch.equal(ops.gather_rows(src.to(DEV), 5, 20, idx.to(DEV)).cpu(), src[idx][:, 5:25])
+    assert torch.equal(ops.gather_rows(src.to(DEV), 8, 32).cpu(), src[:, 8:40])
+    assert torch.equal(ops.gather_rows(src.to(DEV), idx=idx.to(DEV)).cpu(), src[idx])
