@@ -117,11 +117,12 @@ def conv_roofline(ops, steps, alg_gf_step, prefer_dtype, batch=None, precision=N
     all_ms = sum(v[0] for v in per.values()) / max(steps, 1)
     kname = KNAME.get(dom[0], str(dom[0]))
     traffic, traffic_note = None, None
-    tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")        # measured separately (rocprofv3 --pmc passes), see DESIGN.md
+    # measured separately (rocprofv3 --pmc passes, tools/pmc_passes.sh), one file per precision mode; see DESIGN.md
+    tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json" if precision in (None, "fp16") else "pmc_traffic_%s.json" % precision)
     if os.path.isfile(tpath):
         try:
             tj = json.load(open(tpath))
-            ent = tj.get(kname + (" " + DTNAME[dom[1]] if dom[1] == 2 else ""), tj.get(kname, {}))
+            ent = tj.get(kname + (" " + DTNAME[dom[1]] if dom[1] == 2 else ""), {})
             if tj.get("kernel_sources_sha16") == kernel_sources_sha() and tj.get("batch") == batch and tj.get("precision") == precision:
                 traffic = ent.get("hbm_bytes_per_launch")
                 traffic_note = "rocprofv3 --pmc passes of this bench at %s (profiles/pmc_traffic.json), kernel sources unchanged since" % tj.get("measured_at", "?")

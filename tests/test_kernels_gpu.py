@@ -651,7 +651,8 @@ def test_pack_weights_on_device_matches_host_packing(dtype_name, sn):
     # sigma: fp64 sums on the device vs torch's fp32 mv/dot on the host → 1e-6 relative; plus one rounding of the storage type
     tol = {"fp32": 3e-6, "fp16": 1.5e-3, "fp16x3": 3e-6}[dtype_name]
     assert (a - b).abs().max().item() <= tol * b.abs().max().item()
-    assert float(a[70:].abs().max()) == 0.0 and float(a[:, :, :, 40:].abs().max()) == 0.0           # zero padding
+    assert a.shape[0] >= 72 and float(a[70:].abs().max()) == 0.0                                        # zero padding (cout 70 → 72 / 96)
+    assert a.shape[3] == 40 or float(a[:, :, :, 40:].abs().max()) == 0.0                               # (cin 40 → 64 in split-half)
 
 
 def test_pack_wsq_linear_and_gather_rows():

@@ -18,10 +18,10 @@ def main():
     out = {}
     for b in re.split(r"\n(?=\S)", txt):
         lines = b.strip().split("\n")
-        m = re.match(r"void conv_dma_kernel<(\d+), (\d+), (\d+), (\d+), (\d+), (\d+), 0(?:, (\d+))?>", lines[0])
+        m = re.match(r"void conv_dma_kernel<(\d+), (\d+), (\d+), (\d+), (\d+), (\d+), 0(?:, (\w+))?>", lines[0])
         if not m:
             continue
-        x3 = m.group(7) not in (None, "0")
+        x3 = m.group(7) in ("true", "1")
         c = {}
         for l in lines[1:]:
             q = re.match(r"\s+(\S+)\s+mean/dispatch\s+([\d.]+)\s+dispatches (\d+)", l)
