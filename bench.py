@@ -8,6 +8,10 @@
 One "step" = one pass of the whole hot path (ResNet-45 + TextViT encoder → TSPGAN over all glyphs → TSPSRNet) over one
 batch of synthetic 32x512 LR strips per GPU — by default the configuration BASELINE.json's metric is quoted on: batch 256
 per GPU, 16 glyphs per image, inputs resident in HBM, random-init seeded checkpoints of the reference's exact architecture.
+The headline is measured in the precision mode that MEETS the north-star parity bar (<= 1e-3 max-abs vs the reference's CPU
+forward, character indices bit-exact): "fp16x3" — split-half (hi, lo) storage, every multiply evaluated as hi*hi + hi*lo +
+lo*hi on the fp16 MFMA with fp32 accumulation.  The plain fp16 storage mode (2.5x faster, ~1e-2 deviation) and the exact
+fp32 mode are timed in the same run and reported under "secondary", all three with their measured deviation under "parity".
 (`--batch 64` is BASELINE configs[1]; `--gpus 8 --batch 128` is configs[2].)  N>1: weak scaling, every rank processes its
 own batch and the post-processed SR outputs (uint8 BGR, test_sr.py:198-200) are all-gathered over RCCL — the one collective
 of the path.  Rank 0 prints ONE JSON line.
@@ -42,7 +46,13 @@ KNAME = {1: "conv_igemm_kernel (register-staged)", 3: "conv_skinny_f32_kernel", 
          18: "conv_dma_kernel<128,256,2,4,3,16>", 19: "conv_dma_kernel<64,256,1,8,3,16>", 20: "conv_dma_kernel<128,512,2,8,2,16>",
          21: "conv_dma_kernel<64,512,1,8,2,16>", 22: "conv_dma_kernel<256,256,2,4,2,16>", 26: "conv_dma_kernel<128,128,2,4,4,16>",
          32: "conv_strip_kernel<256,256,4,4>", 33: "conv_strip_kernel<64,512,1,8>", 34: "conv_strip_kernel<128,256,2,4>"}
+KNAME_X3 = {22: "conv_dma_kernel<256,256,2,4,2,16>", 23: "conv_dma_kernel<128,512,2,4,2,16>"}     # split-half ids 6 / 7: the 8-wave tiles
 DTNAME = {0: "f32", 1: "f16", 2: "f16x3"}
+
+
+def kname(kid, dt):
+    return (KNAME_X3.get(kid) if dt == 2 else None) or KNAME.get(kid, str(kid))
+
 DTPEAK = {0: PEAK_F32_TFLOPS, 1: PEAK_F16_TFLOPS, 2: PEAK_F16X3_TFLOPS}
 # sources whose content decides the dominant kernel's HBM traffic: the PMC figure in profiles/pmc_traffic.json is reported
 # only while these files are the ones it was measured on (else it is stale and `traffic` is null)
@@ -65,7 +75,9 @@ def parse():
     ap.add_argument("--config", default="sr", choices=["sr", "gan", "mixed"], help="sr: the headline path; gan: configs[3]; mixed: configs[4]")
     ap.add_argument("--batch", type=int, default=256, help="images per GPU (the metric's batch 256; configs[1]: 64; configs[2]: 128 on 8 GPUs)")
     ap.add_argument("--glyphs", type=int, default=16, help="glyphs per image (SURVEY.md §8d: n=16)")
-    ap.add_argument("--precision", default="fp16", choices=["fp16", "fp32", "fp16x3"])
+    ap.add_argument("--precision", default="fp16x3", choices=["fp16x3", "fp16", "fp32"],
+                    help="fp16x3 (default): split-half storage, the throughput mode that meets the 1e-3 parity bar; fp16: BASELINE configs[1]'s "
+                         "storage type (reported as a secondary figure with its measured deviation); fp32: exact fp32 MFMA")
     ap.add_argument("--cpu-images", type=int, default=4, help="images timed on the host CPU oracle (0 = skip); ~3.5 s each on 32 threads")
     ap.add_argument("--no-secondary", action="store_true", help="skip the secondary throughput measurements")
     ap.add_argument("--cpu-threads", type=int, default=32, help="cap on host threads for the CPU baseline")
@@ -115,14 +127,14 @@ def conv_roofline(ops, steps, alg_gf_step, prefer_dtype, batch=None, precision=N
     achieved = dom_fl / max(dom_ms, 1e-9) / 1e9                        # FLOP/ms/1e9 == TFLOP/s (algorithmic FLOPs)
     main_ms = sum(v[0] for k, v in per.items() if k[1] == prefer_dtype) / max(steps, 1)
     all_ms = sum(v[0] for v in per.values()) / max(steps, 1)
-    kname = KNAME.get(dom[0], str(dom[0]))
+    kn = kname(dom[0], dom[1])
     traffic, traffic_note = None, None
     # measured separately (rocprofv3 --pmc passes, tools/pmc_passes.sh), one file per precision mode; see DESIGN.md
     tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json" if precision in (None, "fp16") else "pmc_traffic_%s.json" % precision)
     if os.path.isfile(tpath):
         try:
             tj = json.load(open(tpath))
-            ent = tj.get(kname + (" " + DTNAME[dom[1]] if dom[1] == 2 else ""), {})
+            ent = tj.get(kn + (" " + DTNAME[dom[1]] if dom[1] == 2 else ""), {})
             if tj.get("kernel_sources_sha16") == kernel_sources_sha() and tj.get("batch") == batch and tj.get("precision") == precision:
                 traffic = ent.get("hbm_bytes_per_launch")
                 traffic_note = "rocprofv3 --pmc passes of this bench at %s (profiles/pmc_traffic.json), kernel sources unchanged since" % tj.get("measured_at", "?")
@@ -134,7 +146,7 @@ def conv_roofline(ops, steps, alg_gf_step, prefer_dtype, batch=None, precision=N
     return {
         "bound": "mfma", "achieved": round(achieved, 2), "peak": round(peak, 1), "unit": "TFLOP/s",
         "frac": round(achieved / peak, 4), "traffic": traffic, "traffic_source": traffic_note,
-        "kernel": kname + " " + DTNAME[dom[1]],
+        "kernel": kn + " " + DTNAME[dom[1]],
         "launches_per_step": dom_n // max(steps, 1),
         "avg_launch_ms": round(dom_ms / max(dom_n, 1), 4),
         "flops_per_launch_avg": round(dom_fl / max(dom_n, 1), 1),
@@ -144,7 +156,7 @@ def conv_roofline(ops, steps, alg_gf_step, prefer_dtype, batch=None, precision=N
             "ms_per_step": round(main_ms, 3), "ms_per_step_all_dtypes": round(all_ms, 3),
             "algorithmic_gflop_per_step": round(alg_gf_step, 1),
             "launched_gflop_per_step": round(sum(v[1] for v in per.values()) / max(steps, 1) / 1e9, 1),
-            "by_kernel_ms_per_step": {KNAME.get(k[0], str(k[0])) + " " + DTNAME[k[1]]: round(v[0] / max(steps, 1), 3)
+            "by_kernel_ms_per_step": {kname(k[0], k[1]) + " " + DTNAME[k[1]]: round(v[0] / max(steps, 1), 3)
                                       for k, v in sorted(per.items())},
         },
     }, peak

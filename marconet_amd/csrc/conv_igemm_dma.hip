@@ -374,7 +374,8 @@ static int launch_dma_id(int id, const ConvArgs& a, hipStream_t st) {
             case 3: return launch_dma_cfg<64, 256, 1, 8, 3, 16, 0, true>(a, st);
             case 4: return launch_dma_cfg<128, 512, 2, 8, 2, 16, 0, true>(a, st);
             case 5: return launch_dma_cfg<64, 512, 1, 8, 2, 16, 0, true>(a, st);
-            case 6: return launch_dma_cfg<256, 256, 2, 4, 2, 16, 0, true>(a, st);
+            case 6: return launch_dma_cfg<256, 256, 2, 4, 2, 16, 0, true>(a, st);          // 8 waves, 128x64 per wave: AUTO for cout >= 256
+            case 7: return launch_dma_cfg<128, 512, 2, 4, 2, 16, 0, true>(a, st);          // 8 waves, 64x128 per wave: AUTO for cout 128
             case 10: return launch_dma_cfg<128, 128, 2, 4, 4, 16, 0, true>(a, st);
             default: return mnet_fail(MNET_E_ARG, "conv: LDS-DMA tile configuration %d has no split-half form", id);
         }
@@ -406,6 +407,13 @@ int conv_dma_pick(const ConvArgs& a) {
     // a launch that would leave a quarter or more of the CUs without a tile (a strip at a time: 4096-16384 pixels) takes the
     // 128x128 tile instead: twice the workgroups (same k order, same bits)
     const long long t128 = (a.npix + 127) / 128, t256 = (a.npix + 255) / 256;
+    // split-half (fp16x3): the 8-wave forms of the two big tiles.  Three products per slab need a third set of operand
+    // fragments live: the 16-wave tiles (128 VGPRs per wave) spill (59 / 133 VGPRs) and park 62 % of their wave cycles in
+    // s_waitcnt / barriers; with 2 waves per SIMD and 256 VGPRs the same tiles run 19 % faster (measured: 446 vs 372 TFLOP/s
+    // algorithmic on the 256x256 tile, B = 64) — the opposite of the f16 kernel, where the 16-wave form wins by 6 %.
+    static const int env_x3_16w = [] { const char* e = getenv("MNET_X3_16WAVE"); return e ? atoi(e) : 0; }();                 // A/B knob
+    static const int env_x3_128 = [] { const char* e = getenv("MNET_X3_CFG128"); return e ? atoi(e) : 7; }();                 // A/B knob
+    if (a.split && big && !env_x3_16w && a.cout >= 128) return a.cout >= 256 ? 6 : env_x3_128;
     if (a.cout >= 256) return big ? env_big256 : (t128 * ((a.cout + 255) / 256) < 200 ? 10 : 1);
     if (a.cout >= 128) return big ? 4 : (t256 * ((a.cout + 127) / 128) < 200 ? 10 : 2);
     return big ? 5 : 3;
