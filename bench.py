@@ -45,6 +45,7 @@ GF_F16_PER_GLYPH = GF_GAN + GF_SR_PRIOR
 KNAME = {1: "conv_igemm_kernel (register-staged)", 3: "conv_skinny_f32_kernel", 16: "conv_dma_kernel<256,256,4,4,2,16>", 17: "conv_dma_kernel<256,128,4,2,3,16>",
          18: "conv_dma_kernel<128,256,2,4,3,16>", 19: "conv_dma_kernel<64,256,1,8,3,16>", 20: "conv_dma_kernel<128,512,2,8,2,16>",
          21: "conv_dma_kernel<64,512,1,8,2,16>", 22: "conv_dma_kernel<256,256,2,4,2,16>", 26: "conv_dma_kernel<128,128,2,4,4,16>",
+         24: "conv_dma_kernel<256,256,4,4,2,16,spread>", 25: "conv_dma_kernel<128,512,2,8,2,16,spread>",
          32: "conv_strip_kernel<256,256,4,4>", 33: "conv_strip_kernel<64,512,1,8>", 34: "conv_strip_kernel<128,256,2,4>"}
 KNAME_X3 = {22: "conv_dma_kernel<256,256,2,4,2,16>", 23: "conv_dma_kernel<128,512,2,4,2,16>"}     # split-half ids 6 / 7: the 8-wave tiles
 DTNAME = {0: "f32", 1: "f16", 2: "f16x3"}

@@ -29,7 +29,10 @@
 //     with twice the channels, so one 128-byte slab row is one 32-channel block: chunks 0-3 hi, chunks 4-7 lo — and every slab is
 //     multiplied three times (hi*hi, hi*lo, lo*hi) from the one LDS image: 1.5x the MFMA work per slab, per barrier and per byte
 //     moved of the f16 kernel.
-template <int BC, int BP, int WC, int WP, int STAGES, int MF = 16, int DBG = 0, bool X3 = false>
+// SPREAD (hot iterations of 2-stage tiles): instead of issuing all of a slab's DMA pieces right after the slab barrier — when every
+//     wave of the workgroup does the same and the matrix pipe idles — the weight pieces go out after the first third / half of
+//     the slab's multiplies and the activation pieces after the second.
+template <int BC, int BP, int WC, int WP, int STAGES, int MF = 16, int DBG = 0, bool X3 = false, bool SPREAD = false>
 __global__ void __launch_bounds__(WC * WP * 64, WC * WP / 4) conv_dma_kernel(const ConvArgs p) {
     constexpr int NW = WC * WP;                          // waves per workgroup (8 or 16)
     constexpr int FC = BC / WC / 16, FP = BP / WP / 16;
@@ -39,6 +42,7 @@ __global__ void __launch_bounds__(WC * WP * 64, WC * WP / 4) conv_dma_kernel(con
     constexpr unsigned OOB = 0x80000000u;                // beyond every num_records used below
     static_assert(NW == 8 || NW == 16, "8 or 16 waves");
     static_assert(!X3 || MF == 16, "the split-half form uses v_mfma_f32_16x16x32_f16");
+    static_assert(!SPREAD || (STAGES == 2 && MF == 16 && DBG == 0), "SPREAD: production 2-stage tiles only");
     static_assert(WJ >= 1 && XJ >= 1 && WJ * 8 * NW == BC && XJ * 8 * NW == BP, "tile / wave-count mismatch");
     static_assert(STAGES == 2 || ((STAGES == 3 || STAGES == 4) && NDMA >= 4 && NDMA <= 6), "vmcnt immediates below cover 4-6 DMAs per slab, up to 3 slabs in flight");
     static_assert((BC / WC) % 64 == 0 && (BP / WP) % 32 == 0, "the channel permutation works on 64-channel blocks of a wave tile");
@@ -128,22 +132,29 @@ __global__ void __launch_bounds__(WC * WP * 64, WC * WP / 4) conv_dma_kernel(con
         cur_c = 0; cur_s = 0; cur_tap = 0; cur_tpx = 0; cur_k = 0;
     };
 
-    auto issue_slab = [&](int stage) __attribute__((always_inline)) {
+    // one k-slab = WJ weight pieces + XJ activation pieces (1 KiB per wave-instruction each); issue_w / issue_x may be called apart
+    // (SPREAD) — issue_x advances the slab cursor
+    auto issue_w = [&](int stage) __attribute__((always_inline)) {
         unsigned char* sw_ = smem + stage * STAGE;
-        unsigned char* sx_ = sw_ + BC * 128;
         // k-slab order: 64-channel slice OUTER, filter tap INNER — the 9 taps of a 3x3 filter re-read the same three input
         // rows of one 64-channel slice back to back (≈100 KB per tile) instead of coming back to them after a pass over all
         // channels, so the re-reads, and the rows shared with the vertically neighbouring tiles, hit in the XCD's L2.
         const unsigned kb = (unsigned)(cur_tap * p.cin + cur_c) * 2u;
-        if constexpr (DBG == 2) { if (cur_k > 0) { cur_k += 64; return; } }   // DIAGNOSTIC: no DMA after a tile's first slab
+        if constexpr (DBG == 2) { if (cur_k > 0) return; }   // DIAGNOSTIC: no DMA after a tile's first slab
         const __amdgpu_buffer_rsrc_t rW = __builtin_amdgcn_make_buffer_rsrc((void*)uni64(bW), 0, __builtin_amdgcn_readfirstlane(nW), 0x00020000);
 #pragma unroll
         for (int j = 0; j < WJ; ++j) {
             const unsigned vo = woff[j] == OOB ? OOB : woff[j] + kb;
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rW, (lds_void*)(sw_ + (wave + NW * j) * 1024), 16, vo, 0, 0, 0);
         }
+    };
+    auto issue_x = [&](int stage) __attribute__((always_inline)) {
+        unsigned char* sx_ = smem + stage * STAGE + BC * 128;
+        bool skip = false;
+        if constexpr (DBG == 2) skip = cur_k > 0;
         const unsigned tapbit = 1u << cur_tap;
-        if (cur_c >= p.c0) {                             // wave-uniform: second concat source
+        if (skip) {
+        } else if (cur_c >= p.c0) {                      // wave-uniform: second concat source
             const unsigned uni = (unsigned)(cur_tpx * p.c1 * 2 + (cur_c - p.c0) * 2);
             const __amdgpu_buffer_rsrc_t rX1 = __builtin_amdgcn_make_buffer_rsrc((void*)uni64(bX1), 0, __builtin_amdgcn_readfirstlane(nX1), 0x00020000);
 #pragma unroll
@@ -165,6 +176,7 @@ __global__ void __launch_bounds__(WC * WP * 64, WC * WP / 4) conv_dma_kernel(con
         if (++cur_s == p.kw) { cur_s = 0; cur_tpx += p.w - (p.kw - 1); } else { ++cur_tpx; }
         if (cur_tap == p.kh * p.kw) { cur_tap = 0; cur_s = 0; cur_tpx = 0; cur_c += 64; }
     };
+    auto issue_slab = [&](int stage) __attribute__((always_inline)) { issue_w(stage); issue_x(stage); };
 
     int i_v = blockIdx.x, i_kt = 0, i_stage = 0;         // head of the slab stream: tile, slab, LDS stage
     bool i_live = true;
@@ -225,7 +237,7 @@ __global__ void __launch_bounds__(WC * WP * 64, WC * WP / 4) conv_dma_kernel(con
 
     // split-half slab: 32 channels, hi halves in chunks 0-3 and lo halves in chunks 4-7 of every row; x*w = hi*hi + hi*lo + lo*hi
     // (lo*lo is below fp32 resolution) — the same fp32 accumulators take all three products
-    auto compute_x3 = [&](int stage) __attribute__((always_inline)) {
+    auto compute_x3 = [&](int stage, auto&& after_first, auto&& after_second) __attribute__((always_inline)) {
         const unsigned char* sw_ = smem + stage * STAGE;
         const unsigned char* sx_ = sw_ + BC * 128;
         u32x4 a[FC], bh[FP], bl[FP];
@@ -238,6 +250,7 @@ __global__ void __launch_bounds__(WC * WP * 64, WC * WP / 4) conv_dma_kernel(con
 #pragma unroll
             for (int fb = 0; fb < FP; ++fb)
                 acc[fa][fb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bitcast<f16x8>(a[fa]), bitcast<f16x8>(bh[fb]), acc[fa][fb], 0, 0, 0);
+        after_first();
 #pragma unroll
         for (int f = 0; f < FP; ++f) bl[f] = *reinterpret_cast<const u32x4*>(sx_ + swz_dma(wp * (BP / WP) + f * 16 + l16, 4 + g));
 #pragma unroll
@@ -245,6 +258,7 @@ __global__ void __launch_bounds__(WC * WP * 64, WC * WP / 4) conv_dma_kernel(con
 #pragma unroll
             for (int fb = 0; fb < FP; ++fb)
                 acc[fa][fb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bitcast<f16x8>(a[fa]), bitcast<f16x8>(bl[fb]), acc[fa][fb], 0, 0, 0);
+        after_second();
 #pragma unroll
         for (int f = 0; f < FC; ++f) a[f] = *reinterpret_cast<const u32x4*>(sw_ + swz_dma(wc * (BC / WC) + f * 16 + l16, 4 + g));
 #pragma unroll
@@ -295,9 +309,25 @@ __global__ void __launch_bounds__(WC * WP * 64, WC * WP / 4) conv_dma_kernel(con
             drain = false;
             __builtin_amdgcn_s_barrier();                // ... and every wave is done reading the stage refilled next
             asm volatile("" ::: "memory");
-            issue_hot();
-            if constexpr (X3) compute_x3(c_stage);
-            else { compute_half(c_stage, 0); compute_half(c_stage, 1); }
+            if constexpr (SPREAD) {
+                // the DMA pieces of the next slab ride between the multiplies of this one (sched barriers pin the placement)
+                auto adv = [&]() __attribute__((always_inline)) { i_stage = i_stage == STAGES - 1 ? 0 : i_stage + 1; ++i_kt; };
+                if constexpr (X3) {
+                    compute_x3(c_stage,
+                               [&]() __attribute__((always_inline)) { __builtin_amdgcn_sched_barrier(0); issue_w(i_stage); __builtin_amdgcn_sched_barrier(0); },
+                               [&]() __attribute__((always_inline)) { __builtin_amdgcn_sched_barrier(0); issue_x(i_stage); adv(); __builtin_amdgcn_sched_barrier(0); });
+                } else {
+                    compute_half(c_stage, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+                    issue_w(i_stage); issue_x(i_stage); adv();
+                    __builtin_amdgcn_sched_barrier(0);
+                    compute_half(c_stage, 1);
+                }
+            } else {
+                issue_hot();
+                if constexpr (X3) compute_x3(c_stage, [] {}, [] {});
+                else { compute_half(c_stage, 0); compute_half(c_stage, 1); }
+            }
             c_stage = c_stage == STAGES - 1 ? 0 : c_stage + 1;
         }
         // tail iterations: the slab issued belongs to this workgroup's NEXT tile (set-up + first-slab latency overlap the
@@ -309,7 +339,7 @@ __global__ void __launch_bounds__(WC * WP * 64, WC * WP / 4) conv_dma_kernel(con
             __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");
             inflight += issue_next() - 1;
-            if constexpr (X3) compute_x3(c_stage);
+            if constexpr (X3) compute_x3(c_stage, [] {}, [] {});
             else { compute_half(c_stage, 0); compute_half(c_stage, 1); }
             c_stage = c_stage == STAGES - 1 ? 0 : c_stage + 1;
         }
@@ -335,10 +365,10 @@ __global__ void __launch_bounds__(WC * WP * 64, WC * WP / 4) conv_dma_kernel(con
     }
 }
 
-template <int BC, int BP, int WC, int WP, int STAGES, int MF = 16, int DBG = 0, bool X3 = false>
+template <int BC, int BP, int WC, int WP, int STAGES, int MF = 16, int DBG = 0, bool X3 = false, bool SPREAD = false>
 static int launch_dma_cfg(const ConvArgs& a, hipStream_t st) {
     constexpr int LDS = STAGES * (BC + BP) * 128;
-    auto kern = conv_dma_kernel<BC, BP, WC, WP, STAGES, MF, DBG, X3>;
+    auto kern = conv_dma_kernel<BC, BP, WC, WP, STAGES, MF, DBG, X3, SPREAD>;
     static thread_local DeviceOnce attr_once;      // per instantiation, per thread, per device
     if (!attr_once.done()) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
@@ -376,6 +406,9 @@ static int launch_dma_id(int id, const ConvArgs& a, hipStream_t st) {
             case 5: return launch_dma_cfg<64, 512, 1, 8, 2, 16, 0, true>(a, st);
             case 6: return launch_dma_cfg<256, 256, 2, 4, 2, 16, 0, true>(a, st);          // 8 waves, 128x64 per wave: AUTO for cout >= 256
             case 7: return launch_dma_cfg<128, 512, 2, 4, 2, 16, 0, true>(a, st);          // 8 waves, 64x128 per wave: AUTO for cout 128
+            // (spreading the DMA pieces over the slab's multiplies — ids 8 / 9 of the f16 kernel — was measured here too: the DMA
+            //  state then stays live across the three multiply groups, 167-275 VGPRs spill with scratch reloads inside the
+            //  k-loop, 227 instead of 442 TFLOP/s; not instantiated)
             case 10: return launch_dma_cfg<128, 128, 2, 4, 4, 16, 0, true>(a, st);
             default: return mnet_fail(MNET_E_ARG, "conv: LDS-DMA tile configuration %d has no split-half form", id);
         }
@@ -389,8 +422,8 @@ static int launch_dma_id(int id, const ConvArgs& a, hipStream_t st) {
         case 5: return launch_dma_cfg<64, 512, 1, 8, 2>(a, st);
         case 6: return launch_dma_cfg<256, 256, 2, 4, 2>(a, st);          // 8 waves, 128x64 per wave
         case 7: return launch_dma_cfg<256, 256, 4, 4, 2, 32>(a, st);
-        case 8: return launch_dma_cfg<128, 512, 2, 8, 2, 32>(a, st);
-        case 9: return launch_dma_cfg<64, 512, 1, 8, 2, 32>(a, st);
+        case 8: return launch_dma_cfg<256, 256, 4, 4, 2, 16, 0, false, true>(a, st);       // id 0 with the DMA pieces issued between the two half slabs
+        case 9: return launch_dma_cfg<128, 512, 2, 8, 2, 16, 0, false, true>(a, st);       // id 4, same
         case 10: return launch_dma_cfg<128, 128, 2, 4, 4>(a, st);          // small launches: twice the workgroups of ids 1 / 2, 3 slabs in flight
         case 11: return launch_dma_cfg<256, 256, 4, 4, 2, 16, 4>(a, st);  // DIAGNOSTIC: all tiles store over tile 0; stamps after tile 0
         case 12: return launch_dma_cfg<256, 256, 4, 4, 2, 16, 5>(a, st);  // DIAGNOSTIC: no output stores; stamps after tile 0
@@ -403,7 +436,7 @@ static int launch_dma_id(int id, const ConvArgs& a, hipStream_t st) {
 
 int conv_dma_pick(const ConvArgs& a) {
     const bool big = a.npix >= 256 * 256;
-    static const int env_big256 = [] { const char* e = getenv("MNET_DMA_CFG_BIG256"); return e ? atoi(e) : 0; }();   // A/B knob
+    static const int env_big256 = [] { const char* e = getenv("MNET_DMA_CFG_BIG256"); return e ? atoi(e) : 8; }();   // A/B knob
     // a launch that would leave a quarter or more of the CUs without a tile (a strip at a time: 4096-16384 pixels) takes the
     // 128x128 tile instead: twice the workgroups (same k order, same bits)
     const long long t128 = (a.npix + 127) / 128, t256 = (a.npix + 255) / 256;
@@ -412,10 +445,14 @@ int conv_dma_pick(const ConvArgs& a) {
     // s_waitcnt / barriers; with 2 waves per SIMD and 256 VGPRs the same tiles run 19 % faster (measured: 446 vs 372 TFLOP/s
     // algorithmic on the 256x256 tile, B = 64) — the opposite of the f16 kernel, where the 16-wave form wins by 6 %.
     static const int env_x3_16w = [] { const char* e = getenv("MNET_X3_16WAVE"); return e ? atoi(e) : 0; }();                 // A/B knob
-    static const int env_x3_128 = [] { const char* e = getenv("MNET_X3_CFG128"); return e ? atoi(e) : 7; }();                 // A/B knob
-    if (a.split && big && !env_x3_16w && a.cout >= 128) return a.cout >= 256 ? 6 : env_x3_128;
+    static const int env_x3_128 = [] { const char* e = getenv("MNET_X3_CFG128"); return e ? atoi(e) : 7; }();                 // A/B knobs
+    static const int env_x3_256 = [] { const char* e = getenv("MNET_X3_CFG256"); return e ? atoi(e) : 6; }();
+    if (a.split && big && a.cout >= 128) return env_x3_16w ? (a.cout >= 256 ? 0 : 4) : (a.cout >= 256 ? env_x3_256 : env_x3_128);
+    // f16 big tiles: ids 8 / 9 = ids 0 / 4 with the next slab's DMA pieces issued between the two half slabs instead of right after
+    // the barrier (+2.8 % on the 256x256 tile: 1140 vs 1109 TFLOP/s, B = 64; same MFMA sequence, same bits)
+    static const int env_big128 = [] { const char* e = getenv("MNET_DMA_CFG_BIG128"); return e ? atoi(e) : 9; }();   // A/B knob
     if (a.cout >= 256) return big ? env_big256 : (t128 * ((a.cout + 255) / 256) < 200 ? 10 : 1);
-    if (a.cout >= 128) return big ? 4 : (t256 * ((a.cout + 127) / 128) < 200 ? 10 : 2);
+    if (a.cout >= 128) return big ? env_big128 : (t256 * ((a.cout + 127) / 128) < 200 ? 10 : 2);
     return big ? 5 : 3;
 }
 

@@ -432,7 +432,7 @@ def test_conv_lds_dma_every_tile_config(cfg, shape):
     d = (y_cfg.float() - y_reg.float()).abs()
     assert float(d.max()) <= 2.0 ** -9 * float(y_reg.float().abs().max()), "cfg %d: max diff %g" % (cfg, float(d.max()))
     assert float((d > 0).float().mean()) < 0.2
-    if cfg < 7:    # production configurations: bit-identical to each other (what makes results independent of the batch size)
+    if cfg != 7:   # production configurations (7: the 32x32x16 MFMA experiment): bit-identical to each other — results do not depend on the batch size
         y_auto = ops.conv2d(x0, _pack_w(wt, dtype), cout, k, k, (1, 1), (k // 2, k // 2), algo=2, **kw)
         assert torch.equal(y_cfg, y_auto), "tile configuration %d differs from the auto-picked configuration" % cfg
 
