@@ -75,7 +75,11 @@ __global__ void __launch_bounds__(WC * WP * 64, WC * WP / 4) conv_dma_kernel(con
         return ((unsigned long long)hi << 32) | lo;
     };
     unsigned woff[WJ];                                   // byte offset of this lane's weight chunk at k-slab 0
-    unsigned xb0[XJ], xb1[XJ], xmask[XJ];                // activation rows: offset of (tap 0, channel 0) per concat source; valid-tap bits
+    unsigned xpx[XJ], xmask[XJ];                         // activation rows: input pixel of tap 0 (relative to the tile's first image); valid-tap bits
+    // 16-byte slot inside the 128-byte slab row, XOR-swizzled on the source side.  Row (wave + NW j)*8 + rg → (row >> 1) & 7 =
+    // 4*(wave & 1) + (rg >> 1) for every j (NW is even): ONE value per lane, not one per piece
+    const unsigned lcb = (unsigned)((pc ^ (((wave & 1) << 2) + (rg >> 1))) << 4);
+    static_assert(NW % 2 == 0, "lcb is piece-independent only for an even wave count");
     int cur_c = 0, cur_s = 0, cur_tap = 0, cur_tpx = 0, cur_k = 0;   // wave-uniform k-slab cursor
     const long long img0 = (long long)p.h * p.w * p.c0 * 2, img1 = (long long)p.h * p.w * p.c1 * 2;
 
@@ -108,16 +112,14 @@ __global__ void __launch_bounds__(WC * WP * 64, WC * WP / 4) conv_dma_kernel(con
         for (int j = 0; j < XJ; ++j) {
             const int row = (wave + NW * j) * 8 + rg;
             const int pix = pix0 + row;
-            const int lcb = (pc ^ ((row >> 1) & 7)) * 16;
-            xb0[j] = 0; xb1[j] = 0; xmask[j] = 0;
+            xpx[j] = 0; xmask[j] = 0;
             if (pix < p.npix) {
                 const int n = pix / p.howo, rem = pix - n * p.howo;
                 const int oh = rem / p.wo, ow = rem - oh * p.wo;
                 const int ih0 = oh * p.sh - p.ph, iw0 = ow * p.sw - p.pw;
                 const int px = ((n - n_first) * p.h + ih0) * p.w + iw0;
                 const int vw = p.valid_w ? min(p.valid_w[n], p.w) : p.w;
-                xb0[j] = (unsigned)(px * p.c0 * 2 + lcb);
-                xb1[j] = (unsigned)(px * p.c1 * 2 + lcb);
+                xpx[j] = (unsigned)px;          // may be negative (padding taps); |px| < 2^23 and |px * channels * 2| < 2^31 (eligibility): mul_i24 is exact
                 // taps enumerated t = r*kw + q; fixed 8-trip loops (kh, kw <= 8) so everything stays in registers
                 unsigned cm = 0, m = 0;
 #pragma unroll
@@ -155,20 +157,20 @@ __global__ void __launch_bounds__(WC * WP * 64, WC * WP / 4) conv_dma_kernel(con
         const unsigned tapbit = 1u << cur_tap;
         if (skip) {
         } else if (cur_c >= p.c0) {                      // wave-uniform: second concat source
-            const unsigned uni = (unsigned)(cur_tpx * p.c1 * 2 + (cur_c - p.c0) * 2);
+            const unsigned uni = (unsigned)(cur_tpx * p.c1 * 2 + (cur_c - p.c0) * 2) + lcb, cb = (unsigned)p.c1 * 2u;
             const __amdgpu_buffer_rsrc_t rX1 = __builtin_amdgcn_make_buffer_rsrc((void*)uni64(bX1), 0, __builtin_amdgcn_readfirstlane(nX1), 0x00020000);
 #pragma unroll
             for (int j = 0; j < XJ; ++j) {
-                const unsigned vo = (xmask[j] & tapbit) ? xb1[j] + uni : OOB;
+                const unsigned vo = (xmask[j] & tapbit) ? (unsigned)__mul24((int)xpx[j], (int)cb) + uni : OOB;
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(rX1, (lds_void*)(sx_ + (wave + NW * j) * 1024), 16, vo, 0, 0, 0);
             }
         } else {
-            const unsigned uni = (unsigned)(cur_tpx * p.c0 * 2 + cur_c * 2);
+            const unsigned uni = (unsigned)(cur_tpx * p.c0 * 2 + cur_c * 2) + lcb, cb = (unsigned)p.c0 * 2u;
             const __amdgpu_buffer_rsrc_t rX0 = __builtin_amdgcn_make_buffer_rsrc((void*)uni64(bX0), 0, __builtin_amdgcn_readfirstlane(nX0), 0x00020000);
 #pragma unroll
             for (int j = 0; j < XJ; ++j) {
-                unsigned vo = (xmask[j] & tapbit) ? xb0[j] + uni : OOB;
-                if constexpr (DBG == 1) vo = (xb0[j] & 0x3ffffu) + (unsigned)(cur_c * 2);   // DIAGNOSTIC: activations from a 256 KiB window
+                unsigned vo = (xmask[j] & tapbit) ? (unsigned)__mul24((int)xpx[j], (int)cb) + uni : OOB;
+                if constexpr (DBG == 1) vo = (((unsigned)__mul24((int)xpx[j], (int)cb) + lcb) & 0x3ffffu) + (unsigned)(cur_c * 2);   // DIAGNOSTIC: activations from a 256 KiB window
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(rX0, (lds_void*)(sx_ + (wave + NW * j) * 1024), 16, vo, 0, 0, 0);
             }
         }
@@ -314,8 +316,8 @@ __global__ void __launch_bounds__(WC * WP * 64, WC * WP / 4) conv_dma_kernel(con
                 auto adv = [&]() __attribute__((always_inline)) { i_stage = i_stage == STAGES - 1 ? 0 : i_stage + 1; ++i_kt; };
                 if constexpr (X3) {
                     compute_x3(c_stage,
-                               [&]() __attribute__((always_inline)) { __builtin_amdgcn_sched_barrier(0); issue_w(i_stage); __builtin_amdgcn_sched_barrier(0); },
-                               [&]() __attribute__((always_inline)) { __builtin_amdgcn_sched_barrier(0); issue_x(i_stage); adv(); __builtin_amdgcn_sched_barrier(0); });
+                               [&]() __attribute__((always_inline)) { __builtin_amdgcn_sched_barrier(0); issue_w(i_stage); issue_x(i_stage); adv(); __builtin_amdgcn_sched_barrier(0); },
+                               [] {});
                 } else {
                     compute_half(c_stage, 0);
                     __builtin_amdgcn_sched_barrier(0);
@@ -406,9 +408,8 @@ static int launch_dma_id(int id, const ConvArgs& a, hipStream_t st) {
             case 5: return launch_dma_cfg<64, 512, 1, 8, 2, 16, 0, true>(a, st);
             case 6: return launch_dma_cfg<256, 256, 2, 4, 2, 16, 0, true>(a, st);          // 8 waves, 128x64 per wave: AUTO for cout >= 256
             case 7: return launch_dma_cfg<128, 512, 2, 4, 2, 16, 0, true>(a, st);          // 8 waves, 64x128 per wave: AUTO for cout 128
-            // (spreading the DMA pieces over the slab's multiplies — ids 8 / 9 of the f16 kernel — was measured here too: the DMA
-            //  state then stays live across the three multiply groups, 167-275 VGPRs spill with scratch reloads inside the
-            //  k-loop, 227 instead of 442 TFLOP/s; not instantiated)
+            case 8: return launch_dma_cfg<256, 256, 2, 4, 2, 16, 0, true, true>(a, st);    // id 6 with the DMA pieces after the first multiply group
+            case 9: return launch_dma_cfg<128, 512, 2, 4, 2, 16, 0, true, true>(a, st);    // id 7, same
             case 10: return launch_dma_cfg<128, 128, 2, 4, 4, 16, 0, true>(a, st);
             default: return mnet_fail(MNET_E_ARG, "conv: LDS-DMA tile configuration %d has no split-half form", id);
         }
@@ -445,8 +446,12 @@ int conv_dma_pick(const ConvArgs& a) {
     // s_waitcnt / barriers; with 2 waves per SIMD and 256 VGPRs the same tiles run 19 % faster (measured: 446 vs 372 TFLOP/s
     // algorithmic on the 256x256 tile, B = 64) — the opposite of the f16 kernel, where the 16-wave form wins by 6 %.
     static const int env_x3_16w = [] { const char* e = getenv("MNET_X3_16WAVE"); return e ? atoi(e) : 0; }();                 // A/B knob
-    static const int env_x3_128 = [] { const char* e = getenv("MNET_X3_CFG128"); return e ? atoi(e) : 7; }();                 // A/B knobs
-    static const int env_x3_256 = [] { const char* e = getenv("MNET_X3_CFG256"); return e ? atoi(e) : 6; }();
+    // ids 8 / 9 = ids 6 / 7 with the next slab's DMA pieces issued after the first of the three multiply groups instead of right
+    // after the barrier: +5.6 % / +3.7 % (438 vs 414 TFLOP/s on the 256x256 tile, same box, B = 64).  (Two insertion points —
+    // weights after the first group, activations after the second — keep the DMA state live across all three groups: 167-275
+    // VGPRs spill with scratch reloads inside the k-loop, 227 TFLOP/s.)
+    static const int env_x3_128 = [] { const char* e = getenv("MNET_X3_CFG128"); return e ? atoi(e) : 9; }();                 // A/B knobs
+    static const int env_x3_256 = [] { const char* e = getenv("MNET_X3_CFG256"); return e ? atoi(e) : 8; }();
     if (a.split && big && a.cout >= 128) return env_x3_16w ? (a.cout >= 256 ? 0 : 4) : (a.cout >= 256 ? env_x3_256 : env_x3_128);
     // f16 big tiles: ids 8 / 9 = ids 0 / 4 with the next slab's DMA pieces issued between the two half slabs instead of right after
     // the barrier (+2.8 % on the 256x256 tile: 1140 vs 1109 TFLOP/s, B = 64; same MFMA sequence, same bits)
@@ -469,6 +474,7 @@ bool conv_dma_eligible(const ConvArgs& a, int dtype) {
     const long long imgs = 512 / a.howo + 2;   // largest pixel tile is 512
     const long long per_img = (long long)a.h * a.w * (a.c0 > a.c1 ? a.c0 : a.c1) * 2;
     if (per_img * imgs >= 0x7fffffffLL) return false;
+    if ((long long)a.h * a.w * imgs >= (1ll << 23) || (a.c0 > a.c1 ? a.c0 : a.c1) * 2 >= (1 << 23)) return false;   // 24-bit signed multiply of (pixel, bytes per pixel)
     if ((long long)256 * a.K * 2 >= 0x40000000LL) return false;
     if ((long long)a.cout * a.K * 2 >= 0x7fffffffLL) return false;
     return true;
