@@ -456,7 +456,7 @@ class TSPSRNet(nn.Module, _Precision):
                 parts.append(ops.nchw_to_nhwc(p.contiguous().float(), dtype))
         if not parts:
             return None
-        return parts[0] if len(parts) == 1 else torch.cat(parts, dim=0)
+        return ops.cat_rows(parts)
 
     # ------------------------------------------------------------------ forward
     def forward(self, lq, priors64, priors32, locs):

@@ -57,6 +57,26 @@ def _need_cuda(*ts):
             raise RuntimeError("marconet_amd: non-contiguous tensor passed to a kernel wrapper")
 
 
+def _raw(t):
+    """split-half tensors are moved by PyTorch as plain halves (twice the channels): cat / index_select over the outer dimension
+    never depend on the (experimental) complex32 support of an operator"""
+    return t.view(torch.float16) if t.dtype == SPLIT_DTYPE else t
+
+
+def cat_rows(parts):
+    """concatenation of NHWC tensors along dim 0 (any storage dtype)"""
+    if len(parts) == 1:
+        return parts[0]
+    out = torch.cat([_raw(p) for p in parts], dim=0)
+    return out.view(SPLIT_DTYPE) if parts[0].dtype == SPLIT_DTYPE else out
+
+
+def take_rows(t, idx):
+    """t[idx] along dim 0 (any storage dtype)"""
+    out = _raw(t).index_select(0, idx)
+    return out.view(SPLIT_DTYPE) if t.dtype == SPLIT_DTYPE else out
+
+
 def on_device(t):
     """context manager: the HIP device of ``t`` becomes the current device (launches and the stream lookup follow the current
     device); a CPU tensor raises — there is no CPU path"""

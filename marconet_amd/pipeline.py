@@ -152,7 +152,7 @@ class MarconetPipeline:
             locs_b = (locs.to(dev).index_select(0, it).float() * (512.0 / wb)).contiguous()
             if gsel:
                 gt = torch.tensor(gsel, device=dev)
-                a, c = p64.index_select(0, gt), p32.index_select(0, gt)
+                a, c = ops.take_rows(p64, gt), ops.take_rows(p32, gt)
             else:
                 a = c = None
             y = self.sr.forward_packed(lq_b, a, c, cb, cb, locs_b, nchw_out=True)

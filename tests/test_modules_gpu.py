@@ -250,6 +250,30 @@ def test_fp16x3_batched_driver_and_batch_invariance(nets, ckpts):
         pipe.set_precision("fp32")
 
 
+def test_fp16x3_mixed_widths_and_reference_call_form(nets, ckpts):
+    """configs[4] in the split-half mode: bucketed widths (row gathers of split-half priors) against the oracle at the bucket width"""
+    from marconet_amd.pipeline import MarconetPipeline
+    widths, counts = [130, 512, 250], [2, 4, 3]
+    lq = synth.make_lq(171, len(widths), widths)
+    labels = [synth.make_labels(180 + i, c) for i, c in enumerate(counts)]
+    locs = synth.make_locs(counts, widths)
+    pipe = MarconetPipeline(*nets, precision="fp16x3")
+    try:
+        outs = pipe.forward_mixed_widths(lq.to(DEV), widths, labels, locs)          # labels / locs on the host
+        worst = 0.0
+        with torch.no_grad():
+            _, _, w = O.encoder_forward(ckpts[0], lq)
+            for b, wd in enumerate(widths):
+                wb = (wd + 63) // 64 * 64
+                _, a, c = O.tspgan_forward(ckpts[1], w[b:b + 1].repeat(counts[b], 1), labels[b])
+                ref = O.tspsr_forward(ckpts[2], lq[b:b + 1, :, :, :wb], [a], [c], locs[b:b + 1] * (512.0 / wb))
+                worst = max(worst, _err(outs[b], ref[0]))
+        _note("sr.cfg5.fp16x3.bucketed.maxabs", worst)
+        assert worst <= TOL
+    finally:
+        pipe.set_precision("fp32")
+
+
 def test_error_behaviour(nets):
     """errors surface as Python exceptions so test_sr.py's try/except…continue (:181-190) keeps working"""
     styles = synth.make_styles(1, 2).to(DEV)
