@@ -139,12 +139,12 @@ def conv_roofline(ops, steps, alg_gf_step, prefer_dtype, batch=None, precision=N
             ent = tj.get(kn + (" " + DTNAME[dom[1]] if dom[1] == 2 else ""), {})
             if tj.get("kernel_sources_sha16") == kernel_sources_sha() and tj.get("batch") == batch and tj.get("precision") == precision:
                 traffic = ent.get("hbm_bytes_per_launch")
-                traffic_note = "rocprofv3 --pmc passes of this bench at %s (profiles/pmc_traffic.json), kernel sources unchanged since" % tj.get("measured_at", "?")
+                traffic_note = "rocprofv3 --pmc passes of this bench at %s (profiles/%s), kernel sources unchanged since" % (tj.get("measured_at", "?"), os.path.basename(tpath))
             else:
-                traffic_note = ("profiles/pmc_traffic.json was measured on other kernel sources or another batch / precision "
-                                "(%s, batch %s, %s): not reported" % (tj.get("measured_at", "round 1"), tj.get("batch", 64), tj.get("precision", "fp16")))
+                traffic_note = ("profiles/%s was measured on other kernel sources or another batch / precision "
+                                "(%s, batch %s, %s): not reported" % (os.path.basename(tpath), tj.get("measured_at", "round 1"), tj.get("batch", 64), tj.get("precision", "fp16")))
         except Exception as e:      # noqa: BLE001
-            traffic_note = "profiles/pmc_traffic.json unreadable: %s" % e
+            traffic_note = "profiles/%s unreadable: %s" % (os.path.basename(tpath), e)
     return {
         "bound": "mfma", "achieved": round(achieved, 2), "peak": round(peak, 1), "unit": "TFLOP/s",
         "frac": round(achieved / peak, 4), "traffic": traffic, "traffic_source": traffic_note,
