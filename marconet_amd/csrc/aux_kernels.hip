@@ -933,16 +933,54 @@ __global__ void __launch_bounds__(256) conv3x3_rgb_kernel(const T* __restrict__ 
     const T* xb = x + (size_t)n * H * W * CIN;
     // stage the patch (zero halo outside the image)
     if constexpr (SPLIT) {
+        // split-half input: converted to fp32 while staged, 32 channels (one split block) at a time — a 43.5 KiB patch instead of
+        // 87 KiB, so three workgroups share a CU instead of one (the kernel is a chain of LDS / global latencies at 4 waves per CU)
         const hs* xs = reinterpret_cast<const hs*>(x) + (size_t)n * H * W * CIN;
-        for (int i = t; i < PH * PW * (CIN / 8); i += 256) {
-            const int c8 = i % (CIN / 8), q = i / (CIN / 8);
-            const int py = q / PW, px = q - py * PW;
-            const int gy = y0 + py, gx = x0 + px;
-            float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-            if ((unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W) unpackr<hs>(ldraw<hs>(xs + ((size_t)gy * W + gx) * CIN + c8 * 8), v);
-            *reinterpret_cast<u32x4*>(dyn + lds_off(q, 2 * c8)) = Vec<float>::pack(v);
-            *reinterpret_cast<u32x4*>(dyn + lds_off(q, 2 * c8 + 1)) = Vec<float>::pack(v + 4);
+        const float* wp = reinterpret_cast<const float*>(wgt_);              // [3][9][CIN]
+        auto off32 = [](int q, int c) __attribute__((always_inline)) { return q * 128 + ((c ^ ((q >> 1) & 7)) << 4); };   // 128-byte rows, 8 chunks
+        const int ly_ = t / TW, lx_ = t - ly_ * TW;
+        float b0 = 0.f, b1 = 0.f, b2 = 0.f;
+        for (int half = 0; half < CIN / 32; ++half) {
+            if (half) __syncthreads();
+            for (int i = t; i < PH * PW * 4; i += 256) {
+                const int c8 = i & 3, q = i >> 2;
+                const int py = q / PW, px = q - py * PW;
+                const int gy = y0 + py, gx = x0 + px;
+                float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+                if ((unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W) unpackr<hs>(ldraw<hs>(xs + ((size_t)gy * W + gx) * CIN + half * 32 + c8 * 8), v);
+                *reinterpret_cast<u32x4*>(dyn + off32(q, 2 * c8)) = Vec<float>::pack(v);
+                *reinterpret_cast<u32x4*>(dyn + off32(q, 2 * c8 + 1)) = Vec<float>::pack(v + 4);
+            }
+            __syncthreads();
+#pragma unroll
+            for (int tap = 0; tap < 9; ++tap) {
+                const int q = (ly_ + tap / 3) * PW + lx_ + tap % 3;
+#pragma unroll
+                for (int c = 0; c < 8; ++c) {
+                    const f32x4 v = bitcast<f32x4>(*reinterpret_cast<const u32x4*>(dyn + off32(q, c)));
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const int k = tap * CIN + half * 32 + c * 4 + j;
+                        b0 = fmaf(v[j], wp[k], b0); b1 = fmaf(v[j], wp[9 * CIN + k], b1); b2 = fmaf(v[j], wp[18 * CIN + k], b2);
+                    }
+                }
+            }
         }
+        const int oy_ = ty * TH + ly_, ox_ = tx * TW + lx_;
+        if (oy_ >= H || ox_ >= W) return;
+        float r[8] = {b0 + bias[0], b1 + bias[1], b2 + bias[2], 0.f, 0.f, 0.f, 0.f, 0.f};
+        if (act == MNET_ACT_TANH) { r[0] = tanhf(r[0]); r[1] = tanhf(r[1]); r[2] = tanhf(r[2]); }
+        if (y_nhwc) {
+            T* yp = y_nhwc + (((size_t)n * H + oy_) * W + ox_) * 8;
+            stg16(yp, Vec<float>::pack(r)); stg16(yp + 4, Vec<float>::pack(r + 4));
+        }
+        if (y_nchw) {
+            const size_t plane = (size_t)H * W;
+            float* op = y_nchw + (size_t)n * 3 * plane + (size_t)oy_ * W + ox_;
+#pragma unroll
+            for (int o = 0; o < 3; ++o) op[o * plane] = r[o];
+        }
+        return;
     } else
     for (int i = t; i < PH * PW * CH; i += 256) {
         const int c = i % CH, q = i / CH;
@@ -1030,7 +1068,7 @@ extern "C" int mnet_conv3x3_rgb(const void* x, int32_t dtype, int32_t n, int32_t
             if (e != hipSuccess) return mnet_fail(MNET_E_LAUNCH, "hipFuncSetAttribute(conv3x3_rgb): %s", hipGetErrorString(e));
             attr_once.mark();
         }
-        if (dtype == MNET_F16X2) hipLaunchKernelGGL((conv3x3_rgb_kernel<float, 64, true>), dim3(tiles, n), dim3(256), lds, st, (const float*)x, wgt, bias, (float*)y_nhwc, y_nchw, h, w, act);
+        if (dtype == MNET_F16X2) hipLaunchKernelGGL((conv3x3_rgb_kernel<float, 64, true>), dim3(tiles, n), dim3(256), 10 * 34 * 32 * 4, st, (const float*)x, wgt, bias, (float*)y_nhwc, y_nchw, h, w, act);
         else hipLaunchKernelGGL((conv3x3_rgb_kernel<float, 64>), dim3(tiles, n), dim3(256), lds, st, (const float*)x, wgt, bias, (float*)y_nhwc, y_nchw, h, w, act);
     }
     MNET_LAUNCH_CHECK("conv3x3_rgb");
