@@ -73,12 +73,26 @@ def test_argument_validation_without_device():
     d2.dtype = 1; d2.x0 = 16; d2.wgt = 16; d2.y = 16; d2.n = 64; d2.h = d2.ho = 32; d2.w = d2.wo = 32
     d2.c0 = 64; d2.kh = d2.kw = 3; d2.stride_h = d2.stride_w = 1; d2.pad_h = d2.pad_w = 1
     d2.cout = 256
-    assert lib.mnet_conv2d_plan(ctypes.byref(d2), _lib.ALGO_AUTO) == _lib.ALGO_DMA_CFG0            # 256x256 LDS-DMA tile
+    assert lib.mnet_conv2d_plan(ctypes.byref(d2), _lib.ALGO_AUTO) == _lib.ALGO_DMA_CFG0 + 8        # 256x256 LDS-DMA tile (DMA between the half slabs)
     assert lib.mnet_conv2d_plan(ctypes.byref(d2), _lib.ALGO_STRIP_CFG0) == _lib.ALGO_STRIP_CFG0    # strip form by explicit request
     d2.cout = 64
     assert lib.mnet_conv2d_plan(ctypes.byref(d2), _lib.ALGO_AUTO) == _lib.ALGO_STRIP_CFG0 + 1      # strip kernel, 64x512 tile
     d2.cout = 128
-    assert lib.mnet_conv2d_plan(ctypes.byref(d2), _lib.ALGO_AUTO) == _lib.ALGO_DMA_CFG0 + 4        # 128x512 tile
+    assert lib.mnet_conv2d_plan(ctypes.byref(d2), _lib.ALGO_AUTO) == _lib.ALGO_DMA_CFG0 + 9        # 128x512 tile (same form)
+    # split-half (fp16x3) launches: 128-byte aligned tensors, the 8-wave tiles; no strip kernel
+    d2.dtype = 2; d2.x0 = d2.wgt = d2.y = 128
+    assert lib.mnet_conv2d_plan(ctypes.byref(d2), _lib.ALGO_AUTO) == _lib.ALGO_DMA_CFG0 + 9
+    d2.cout = 256
+    assert lib.mnet_conv2d_plan(ctypes.byref(d2), _lib.ALGO_AUTO) == _lib.ALGO_DMA_CFG0 + 8
+    d2.cout = 64
+    assert lib.mnet_conv2d_plan(ctypes.byref(d2), _lib.ALGO_AUTO) == _lib.ALGO_DMA_CFG0 + 5
+    d2.c0 = 48
+    assert lib.mnet_conv2d_plan(ctypes.byref(d2), _lib.ALGO_AUTO) == -2 and b"split-half" in lib.mnet_last_error()   # c0 % 32
+    d2.c0 = 32
+    assert lib.mnet_conv2d_plan(ctypes.byref(d2), _lib.ALGO_AUTO) == _lib.ALGO_DMA_CFG0 + 5        # one 32-channel block per k-slab
+    d2.x0 = 16
+    assert lib.mnet_conv2d_plan(ctypes.byref(d2), _lib.ALGO_AUTO) == -2                             # 128-byte alignment
+    d2.dtype = 1; d2.x0 = d2.wgt = d2.y = 16; d2.c0 = 64; d2.cout = 128
     d2.n = 4                                                                                       # 4096 pixels: small-launch tile
     assert lib.mnet_conv2d_plan(ctypes.byref(d2), _lib.ALGO_AUTO) == _lib.ALGO_DMA_CFG0 + 10       # 16 tiles of 128x256 → 128x128 tiles
     d2.n = 56                                                                                      # 57344 pixels: 224 tiles of 128x256
