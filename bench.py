@@ -48,7 +48,8 @@ KNAME = {1: "conv_igemm_kernel (register-staged)", 3: "conv_skinny_f32_kernel", 
          24: "conv_dma_kernel<256,256,4,4,2,16,spread>", 25: "conv_dma_kernel<128,512,2,8,2,16,spread>",
          32: "conv_strip_kernel<256,256,4,4>", 33: "conv_strip_kernel<64,512,1,8>", 34: "conv_strip_kernel<128,256,2,4>"}
 KNAME_X3 = {22: "conv_dma_kernel<256,256,2,4,2,16>", 23: "conv_dma_kernel<128,512,2,4,2,16>",      # split-half ids 6 / 7: the 8-wave tiles
-            24: "conv_dma_kernel<256,256,2,4,2,16,spread>", 25: "conv_dma_kernel<128,512,2,4,2,16,spread>"}
+            24: "conv_dma_kernel<256,256,2,4,2,16,spread>", 25: "conv_dma_kernel<128,512,2,4,2,16,spread>",
+            27: "conv_dma_kernel<256,256,2,4,2,16,spread,pipe>", 28: "conv_dma_kernel<128,512,2,4,2,16,spread,pipe>"}
 DTNAME = {0: "f32", 1: "f16", 2: "f16x3"}
 
 

@@ -114,7 +114,8 @@ int mnet_conv2d_nhwc(const mnet_conv_desc* d, void* stream);
  *      (AUTO's choice for >= 65536 output pixels: +2.8 % on the 256x256 tile; same MFMA sequence, same bits)
  *   id 7: id 0 on v_mfma_f32_32x32x16_f16 (experimental)
  *   MNET_F16X2 launches: ids 0-6 and 10 as above on the split-half form, id 7 = 128x512 8w (64x128 per wave), ids 8 / 9 = ids 6 / 7
- *      with the DMA pieces issued after the first multiply group; AUTO takes the 8-wave tiles 8 / 9 for >= 65536 output pixels
+ *      with the DMA pieces issued after the first multiply group, ids 11 / 12 = ids 8 / 9 with the LDS reads placed by scheduling
+ *      hints; AUTO takes the 8-wave tiles 11 (cout >= 256) / 9 (cout 128) for >= 65536 output pixels
  *   id 11-15: diagnostic builds used by tools/wg_timeline.py and tools/conv_bench.py; they produce WRONG results */
 enum { MNET_CONV_ALGO_AUTO = 0, MNET_CONV_ALGO_REG_STAGED = 1, MNET_CONV_ALGO_LDS_DMA = 2,
        MNET_CONV_ALGO_SKINNY = 3 /* fp32 1x1 over <= 512 pixels straight from global memory (the TextViT linears of a small batch;

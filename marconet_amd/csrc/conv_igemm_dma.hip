@@ -32,7 +32,7 @@
 // SPREAD (hot iterations of 2-stage tiles): instead of issuing all of a slab's DMA pieces right after the slab barrier — when every
 //     wave of the workgroup does the same and the matrix pipe idles — the weight pieces go out after the first third / half of
 //     the slab's multiplies and the activation pieces after the second.
-template <int BC, int BP, int WC, int WP, int STAGES, int MF = 16, int DBG = 0, bool X3 = false, bool SPREAD = false>
+template <int BC, int BP, int WC, int WP, int STAGES, int MF = 16, int DBG = 0, bool X3 = false, bool SPREAD = false, bool PIPE = false>
 __global__ void __launch_bounds__(WC * WP * 64, WC * WP / 4) conv_dma_kernel(const ConvArgs p) {
     constexpr int NW = WC * WP;                          // waves per workgroup (8 or 16)
     constexpr int FC = BC / WC / 16, FP = BP / WP / 16;
@@ -247,14 +247,28 @@ __global__ void __launch_bounds__(WC * WP * 64, WC * WP / 4) conv_dma_kernel(con
         for (int f = 0; f < FC; ++f) a[f] = *reinterpret_cast<const u32x4*>(sw_ + swz_dma(wc * (BC / WC) + f * 16 + l16, g));
 #pragma unroll
         for (int f = 0; f < FP; ++f) bh[f] = *reinterpret_cast<const u32x4*>(sx_ + swz_dma(wp * (BP / WP) + f * 16 + l16, g));
+        if constexpr (PIPE) {           // lo activation fragments fetched under the first group's MFMAs (no more registers live than at the second group)
+#pragma unroll
+            for (int f = 0; f < FP; ++f) bl[f] = *reinterpret_cast<const u32x4*>(sx_ + swz_dma(wp * (BP / WP) + f * 16 + l16, 4 + g));
+        }
 #pragma unroll
         for (int fa = 0; fa < FC; ++fa)
 #pragma unroll
             for (int fb = 0; fb < FP; ++fb)
                 acc[fa][fb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bitcast<f16x8>(a[fa]), bitcast<f16x8>(bh[fb]), acc[fa][fb], 0, 0, 0);
-        after_first();
+        if constexpr (PIPE) {
+            __builtin_amdgcn_sched_group_barrier(0x100, FC + FP, 0);       // all hi fragments up front (they are all needed before the pipe fills anyway)
 #pragma unroll
-        for (int f = 0; f < FP; ++f) bl[f] = *reinterpret_cast<const u32x4*>(sx_ + swz_dma(wp * (BP / WP) + f * 16 + l16, 4 + g));
+            for (int i = 0; i < FP; ++i) {
+                __builtin_amdgcn_sched_group_barrier(0x008, FC, 0);        // FC MFMAs ...
+                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);         // ... one lo activation fragment
+            }
+        }
+        after_first();
+        if constexpr (!PIPE) {
+#pragma unroll
+            for (int f = 0; f < FP; ++f) bl[f] = *reinterpret_cast<const u32x4*>(sx_ + swz_dma(wp * (BP / WP) + f * 16 + l16, 4 + g));
+        }
 #pragma unroll
         for (int fa = 0; fa < FC; ++fa)
 #pragma unroll
@@ -367,10 +381,10 @@ __global__ void __launch_bounds__(WC * WP * 64, WC * WP / 4) conv_dma_kernel(con
     }
 }
 
-template <int BC, int BP, int WC, int WP, int STAGES, int MF = 16, int DBG = 0, bool X3 = false, bool SPREAD = false>
+template <int BC, int BP, int WC, int WP, int STAGES, int MF = 16, int DBG = 0, bool X3 = false, bool SPREAD = false, bool PIPE = false>
 static int launch_dma_cfg(const ConvArgs& a, hipStream_t st) {
     constexpr int LDS = STAGES * (BC + BP) * 128;
-    auto kern = conv_dma_kernel<BC, BP, WC, WP, STAGES, MF, DBG, X3, SPREAD>;
+    auto kern = conv_dma_kernel<BC, BP, WC, WP, STAGES, MF, DBG, X3, SPREAD, PIPE>;
     static thread_local DeviceOnce attr_once;      // per instantiation, per thread, per device
     if (!attr_once.done()) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
@@ -410,6 +424,8 @@ static int launch_dma_id(int id, const ConvArgs& a, hipStream_t st) {
             case 7: return launch_dma_cfg<128, 512, 2, 4, 2, 16, 0, true>(a, st);          // 8 waves, 64x128 per wave: AUTO for cout 128
             case 8: return launch_dma_cfg<256, 256, 2, 4, 2, 16, 0, true, true>(a, st);    // id 6 with the DMA pieces after the first multiply group
             case 9: return launch_dma_cfg<128, 512, 2, 4, 2, 16, 0, true, true>(a, st);    // id 7, same
+            case 11: return launch_dma_cfg<256, 256, 2, 4, 2, 16, 0, true, true, true>(a, st);   // id 8 + LDS reads placed by scheduling hints
+            case 12: return launch_dma_cfg<128, 512, 2, 4, 2, 16, 0, true, true, true>(a, st);   // id 9, same
             case 10: return launch_dma_cfg<128, 128, 2, 4, 4, 16, 0, true>(a, st);
             default: return mnet_fail(MNET_E_ARG, "conv: LDS-DMA tile configuration %d has no split-half form", id);
         }
@@ -451,7 +467,9 @@ int conv_dma_pick(const ConvArgs& a) {
     // weights after the first group, activations after the second — keep the DMA state live across all three groups: 167-275
     // VGPRs spill with scratch reloads inside the k-loop, 227 TFLOP/s.)
     static const int env_x3_128 = [] { const char* e = getenv("MNET_X3_CFG128"); return e ? atoi(e) : 9; }();                 // A/B knobs
-    static const int env_x3_256 = [] { const char* e = getenv("MNET_X3_CFG256"); return e ? atoi(e) : 8; }();
+    // id 11 = id 8 with the LDS reads placed by scheduling hints (all hi fragments up front, the lo activation fragments under the
+    // first group's MFMAs): 472 vs 465 TFLOP/s (+1.5 %); the 128x512 tile does not gain (id 12 stays an A/B knob)
+    static const int env_x3_256 = [] { const char* e = getenv("MNET_X3_CFG256"); return e ? atoi(e) : 11; }();
     if (a.split && big && a.cout >= 128) return env_x3_16w ? (a.cout >= 256 ? 0 : 4) : (a.cout >= 256 ? env_x3_256 : env_x3_128);
     // f16 big tiles: ids 8 / 9 = ids 0 / 4 with the next slab's DMA pieces issued between the two half slabs instead of right after
     // the barrier (+2.8 % on the 256x256 tile: 1140 vs 1109 TFLOP/s, B = 64; same MFMA sequence, same bits)

@@ -120,7 +120,7 @@ def test_conv_plain(case):
     _check("split conv %s" % (case,), _from_split(y), ref)
 
 
-@pytest.mark.parametrize("id_", [0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10])
+@pytest.mark.parametrize("id_", [0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12])
 def test_every_lds_dma_tile_configuration(id_):
     """each split-half instantiation of the LDS-DMA kernel, pinned explicitly, with the full epilogue"""
     ops = _ops()
