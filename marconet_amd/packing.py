@@ -178,7 +178,7 @@ def equal_linear_scale(in_channels, lr_mul):
 # structure and the non-tensor leaves as JSON metadata, and a SHA-256 of each holder's parameters so that a blob is never
 # attached to different weights.
 PACK_FORMAT = "marconet_amd.packed.v2"
-PACK_LAYOUT = 2        # bump whenever any holder's _build() changes what it emits (keys, padding, layouts): a blob written by a
+PACK_LAYOUT = 3        # bump whenever any holder's _build() changes what it emits (keys, padding, layouts): a blob written by a
                        # different _build must not attach (it would fail with a KeyError mid-forward, or be read with another layout)
 
 
@@ -207,8 +207,10 @@ def _weights_digest(m):
 
 def _flatten(obj, path, tensors, tree):
     if torch.is_tensor(obj):
-        tree[path] = {"t": "tensor"}
-        tensors[path] = obj.detach().contiguous().cpu().clone()
+        split = obj.dtype == SPLIT_DTYPE          # safetensors has no (hi, lo)-pair dtype: stored as the raw halves, re-tagged on load
+        tree[path] = {"t": "tensor", "split": split}
+        t = obj.detach().contiguous().cpu()
+        tensors[path] = (t.view(torch.float16) if split else t).clone()
     elif isinstance(obj, dict):
         if not all(isinstance(k, str) and "/" not in k for k in obj):
             raise TypeError("packed tree keys must be strings without '/' (at %r)" % path)
@@ -228,7 +230,8 @@ def _flatten(obj, path, tensors, tree):
 def _unflatten(path, get_tensor, tree):
     node = tree[path]
     if node["t"] == "tensor":
-        return get_tensor(path)
+        t = get_tensor(path)
+        return t.view(SPLIT_DTYPE) if node.get("split") else t
     if node["t"] == "dict":
         return {k: _unflatten(path + "/" + k, get_tensor, tree) for k in node["keys"]}
     if node["t"] in ("tuple", "list"):

@@ -467,12 +467,13 @@ def test_generator_distinct_styles_equal_expanded(nets):
     nets[1].set_precision("fp32")
 
 
+@pytest.mark.parametrize("precision", ["fp16", "fp16x3"])
 @pytest.mark.parametrize("output", ["nchw_f32", "u8_bgr"])
-def test_hip_graph_replay_equals_eager(nets, output):
+def test_hip_graph_replay_equals_eager(nets, output, precision):
     """GraphedForward (the whole forward of one batch signature captured in a HIP graph) gives the eager driver's bits, also
     when replayed on new LQ / labels / locations; a different glyph-count signature is refused"""
     from marconet_amd.pipeline import GraphedForward, MarconetPipeline
-    pipe = MarconetPipeline(*nets, precision="fp16")
+    pipe = MarconetPipeline(*nets, precision=precision)
     try:
         counts = [5, 0, 3]
         gf = GraphedForward(pipe, 3, counts, output=output)
@@ -489,7 +490,8 @@ def test_hip_graph_replay_equals_eager(nets, output):
         pipe.set_precision("fp32")
 
 
-def test_packed_blob_drives_the_same_forward(nets, ckpts, tmp_path):
+@pytest.mark.parametrize("precision", ["fp16", "fp16x3"])
+def test_packed_blob_drives_the_same_forward(nets, ckpts, tmp_path, precision):
     """SURVEY §8(f) NEXT-3: modules that attach an offline packed-weights blob (packing.save_packed / load_packed) instead of
     packing at first use give the same bits"""
     from marconet_amd import networks
@@ -498,7 +500,7 @@ def test_packed_blob_drives_the_same_forward(nets, ckpts, tmp_path):
     lq = synth.make_lq(51, 2, [512, 300]).to(DEV)
     labels = [synth.make_labels(52, 4), synth.make_labels(53, 2)]
     locs = synth.make_locs([4, 2], [512, 300])
-    pipe = MarconetPipeline(*nets, precision="fp16")
+    pipe = MarconetPipeline(*nets, precision=precision)
     try:
         want = pipe.forward_batch(lq, labels, locs)
         path = str(tmp_path / "marconet.packed.safetensors")
@@ -506,11 +508,11 @@ def test_packed_blob_drives_the_same_forward(nets, ckpts, tmp_path):
         fresh = [networks.TextContextEncoderV2(), networks.TSPGAN(), networks.TSPSRNet()]
         for m, sd in zip(fresh, ckpts):
             m.load_state_dict(sd, strict=True)
-            m.eval().to(DEV).set_precision("fp16")
+            m.eval().to(DEV).set_precision(precision)
         assert sorted(load_packed(path, encoder=fresh[0], gan=fresh[1], sr=fresh[2])) == keys
         for _, h in [x for m in fresh for x in __import__("marconet_amd.packing", fromlist=["_holders"])._holders(m)]:
             h._build = None                                   # any attempt to re-pack would now raise
-        got = MarconetPipeline(*fresh, precision="fp16").forward_batch(lq, labels, locs)
+        got = MarconetPipeline(*fresh, precision=precision).forward_batch(lq, labels, locs)
         assert torch.equal(got, want)
     finally:
         pipe.set_precision("fp32")

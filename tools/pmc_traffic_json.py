@@ -18,7 +18,7 @@ def main():
     out = {}
     for b in re.split(r"\n(?=\S)", txt):
         lines = b.strip().split("\n")
-        m = re.match(r"void conv_dma_kernel<(\d+), (\d+), (\d+), (\d+), (\d+), (\d+), 0(?:, (\w+))?(?:, (\w+))?>", lines[0])
+        m = re.match(r"void conv_dma_kernel<(\d+), (\d+), (\d+), (\d+), (\d+), (\d+), 0(?:, (\w+))?(?:, (\w+))?(?:, (\w+))?>", lines[0])
         if not m:
             continue
         x3, spread, pipe = m.group(7) in ("true", "1"), m.group(8) in ("true", "1"), m.group(9) in ("true", "1")
