@@ -467,7 +467,7 @@ def test_generator_distinct_styles_equal_expanded(nets):
     nets[1].set_precision("fp32")
 
 
-@pytest.mark.parametrize("precision", ["fp16", "fp16x3"])
+@pytest.mark.parametrize("precision", ["fp16", "fp16x3", "fp32"])
 @pytest.mark.parametrize("output", ["nchw_f32", "u8_bgr"])
 def test_hip_graph_replay_equals_eager(nets, output, precision):
     """GraphedForward (the whole forward of one batch signature captured in a HIP graph) gives the eager driver's bits, also

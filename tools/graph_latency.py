@@ -1,5 +1,5 @@
 """Batch-1 latency of the script-shaped call (test_sr.py:77 loop, one strip at a time): eager launches vs one HIP-graph replay.
-    python tools/graph_latency.py [glyphs=16] [iters=50]"""
+    python tools/graph_latency.py [glyphs=16] [iters=50] [precision=fp16]"""
 import sys
 import time
 
@@ -11,9 +11,14 @@ from marconet_amd.pipeline import GraphedForward, MarconetPipeline    # noqa: E4
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 16
 iters = int(sys.argv[2]) if len(sys.argv) > 2 else 50
+prec = sys.argv[3] if len(sys.argv) > 3 else "fp16"
 torch.manual_seed(0)
-nets = [m.eval().cuda() for m in (networks.TextContextEncoderV2(), networks.TSPGAN(), networks.TSPSRNet())]
-pipe = MarconetPipeline(*nets, precision="fp16")
+from marconet_amd import synthetic                                    # noqa: E402
+nets = [networks.TextContextEncoderV2(), networks.TSPGAN(), networks.TSPSRNet()]
+for m, sd in zip(nets, (synthetic.make_encoder_state_dict(), synthetic.make_gan_state_dict(), synthetic.make_sr_state_dict())):
+    m.load_state_dict(sd, strict=True)              # seeded checkpoints with O(1) activations (default-initialised spectral-norm vectors blow up)
+nets = [m.eval().cuda() for m in nets]
+pipe = MarconetPipeline(*nets, precision=prec, check_finite=False)
 lq = torch.rand(1, 3, 32, 512, device="cuda")
 labels = [torch.randint(0, 6736, (n,))]
 locs = torch.zeros(1, 32)
@@ -36,4 +41,4 @@ eager = clock(lambda: pipe.forward_batch(lq, labels, locs))
 gf = GraphedForward(pipe, 1, [n])
 graphed = clock(lambda: gf(lq, labels, locs))
 same = torch.equal(gf(lq, labels, locs), pipe.forward_batch(lq, labels, locs))
-print("batch 1, %d glyphs, fp16: eager %.2f ms/image, HIP graph %.2f ms/image (%.2fx), identical=%s" % (n, eager, graphed, eager / graphed, same))
+print("batch 1, %d glyphs, %s: eager %.2f ms/image, HIP graph %.2f ms/image (%.2fx), identical=%s" % (n, prec, eager, graphed, eager / graphed, same))
