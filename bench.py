@@ -47,7 +47,7 @@ KNAME = {1: "conv_igemm_kernel (register-staged)", 3: "conv_skinny_f32_kernel", 
          21: "conv_dma_kernel<64,512,1,8,2,16>", 22: "conv_dma_kernel<256,256,2,4,2,16>", 26: "conv_dma_kernel<128,128,2,4,4,16>",
          24: "conv_dma_kernel<256,256,4,4,2,16,spread>", 25: "conv_dma_kernel<128,512,2,8,2,16,spread>",
          32: "conv_strip_kernel<256,256,4,4>", 33: "conv_strip_kernel<64,512,1,8>", 34: "conv_strip_kernel<128,256,2,4>"}
-KNAME_X3 = {22: "conv_dma_kernel<256,256,2,4,2,16>", 23: "conv_dma_kernel<128,512,2,4,2,16>",      # split-half ids 6 / 7: the 8-wave tiles
+KNAME_X3 = {33: "conv_strip_kernel<64,512,1,8,x3>", 22: "conv_dma_kernel<256,256,2,4,2,16>", 23: "conv_dma_kernel<128,512,2,4,2,16>",      # split-half ids 6 / 7: the 8-wave tiles
             24: "conv_dma_kernel<256,256,2,4,2,16,spread>", 25: "conv_dma_kernel<128,512,2,4,2,16,spread>",
             27: "conv_dma_kernel<256,256,2,4,2,16,spread,pipe>", 28: "conv_dma_kernel<128,512,2,4,2,16,spread,pipe>"}
 DTNAME = {0: "f32", 1: "f16", 2: "f16x3"}
@@ -303,6 +303,12 @@ def main():
             n_steps = 1 if prec == "fp32" else a.steps
             secondary["%s_mode_images_per_s" % prec] = round((total_images if kk == B else kk * world) * n_steps / dtk, 3)
             secondary["%s_mode_batch_per_gpu" % prec] = kk
+        # a point in between: only the encoder (5 % of the FLOPs; its style vector w feeds every modulation) in the split-half mode
+        pipe.set_precision("fp16")
+        pipe.encoder.set_precision("fp16x3")
+        step()
+        dtm, _, _ = timed(step, fence, a.steps, world, dev)
+        secondary["fp16_with_fp16x3_encoder_images_per_s"] = round(total_images * a.steps / dtm, 3)
         pipe.set_precision(a.precision)
         secondary["modes"] = ("fp32: exact fp32 MFMA (parity mode); fp16x3: split-half storage, hi*hi + hi*lo + lo*hi on the fp16 MFMA "
                               "(meets the 1e-3 bar, see parity); fp16: one half per element (BASELINE configs[1]'s storage type)")
@@ -356,6 +362,12 @@ def main():
             lg = pipe.encoder(lq[:k])[0]
             par["sr_max_abs_%s" % prec] = round((yk.cpu() - ref_sr).abs().max().item(), 6)
             par["argmax_match_%s" % prec] = round(float((lg.argmax(-1).cpu() == ref_arg).float().mean()), 4)
+        pipe.set_precision("fp16")
+        pipe.encoder.set_precision("fp16x3")
+        yk = pipe.forward_batch(lq[:k], labels[:k], locs[:k])
+        lg = pipe.encoder(lq[:k])[0]
+        par["sr_max_abs_fp16_with_fp16x3_encoder"] = round((yk.cpu() - ref_sr).abs().max().item(), 6)
+        par["argmax_match_fp16_with_fp16x3_encoder"] = round(float((lg.argmax(-1).cpu() == ref_arg).float().mean()), 4)
         pipe.set_precision(a.precision)
         par["bar"] = "north_star: <= 1e-3 max-abs on the SR output, argmax bit-exact (argmax_match == 1.0)"
         out["parity"] = par

@@ -124,7 +124,7 @@ enum { MNET_CONV_ALGO_AUTO = 0, MNET_CONV_ALGO_REG_STAGED = 1, MNET_CONV_ALGO_LD
        MNET_CONV_ALGO_STRIP_CFG0 = 32 /* + id: the 3x3 "strip" LDS-DMA kernel (one activation strip per filter row shared by its
                                         * three taps; id 0: 256x256 tile, id 1: 64x512 tile).  Eligible: 3x3/stride 1/pad 1, one
                                         * source, cout >= 256 (id 0) or < 128 (id 1), >= 65536 output pixels, whole-row tiles.
-                                        * AUTO uses id 1 when eligible (id 0 measured neutral: explicit request only).  Same k order and MFMA as the LDS-DMA kernel → identical bits. */,
+                                        * AUTO uses id 1 when eligible (id 0 measured neutral: explicit request only; MNET_F16X2: id 1 only).  Same k order and MFMA as the LDS-DMA kernel → identical bits. */,
        MNET_CONV_ALGO_FLAG_ONE_TILE = 256 /* OR-ed in: LDS-DMA kernel launched with one workgroup per tile instead of its
                                             * persistent grid (A/B measurements only; same results) */ };
 int mnet_conv2d_nhwc_ex(const mnet_conv_desc* d, int32_t algo, void* stream);

@@ -23,7 +23,10 @@
 
 template <int BP> struct StripCap { static constexpr int MINW = BP == 256 ? 16 : 32; static constexpr int ROWS = BP + 2 * (BP / MINW); };
 
-template <int BC, int BP, int WC, int WP>
+// X3: split-half launch (MNET_F16X2): the tensors are walked as f16 with twice the channels — a strip row / weight row of 128 bytes is
+//     one 32-channel block, hi halves in chunks 0-3, lo halves in chunks 4-7 — and every (slab, tap) is multiplied three times
+//     (hi*hi, hi*lo, lo*hi), exactly like conv_dma_kernel<…, X3>.
+template <int BC, int BP, int WC, int WP, bool X3 = false>
 __global__ void __launch_bounds__(WC * WP * 64, WC * WP / 4) conv_strip_kernel(const ConvArgs p) {
     constexpr int NW = WC * WP;
     constexpr int FC = BC / WC / 16, FP = BP / WP / 16;
@@ -184,6 +187,35 @@ __global__ void __launch_bounds__(WC * WP * 64, WC * WP / 4) conv_strip_kernel(c
                 acc[fa][fb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bitcast<f16x8>(a[fa]), bitcast<f16x8>(b[fb]), acc[fa][fb], 0, 0, 0);
     };
 
+    auto compute_x3 = [&](int wst, int sst, int s) __attribute__((always_inline)) {
+        const unsigned char* sw_ = smem + wst * WBYTES;
+        const unsigned char* ss_ = smem + 2 * WBYTES + sst * SBYTES;
+        u32x4 a[FC], bh[FP], bl[FP];
+#pragma unroll
+        for (int f = 0; f < FC; ++f) a[f] = *reinterpret_cast<const u32x4*>(sw_ + swz_dma(wc * (BC / WC) + f * 16 + l16, g));
+#pragma unroll
+        for (int f = 0; f < FP; ++f) bh[f] = *reinterpret_cast<const u32x4*>(ss_ + swz_dma(srow[f] + s, g));
+#pragma unroll
+        for (int fa = 0; fa < FC; ++fa)
+#pragma unroll
+            for (int fb = 0; fb < FP; ++fb)
+                acc[fa][fb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bitcast<f16x8>(a[fa]), bitcast<f16x8>(bh[fb]), acc[fa][fb], 0, 0, 0);
+#pragma unroll
+        for (int f = 0; f < FP; ++f) bl[f] = *reinterpret_cast<const u32x4*>(ss_ + swz_dma(srow[f] + s, 4 + g));
+#pragma unroll
+        for (int fa = 0; fa < FC; ++fa)
+#pragma unroll
+            for (int fb = 0; fb < FP; ++fb)
+                acc[fa][fb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bitcast<f16x8>(a[fa]), bitcast<f16x8>(bl[fb]), acc[fa][fb], 0, 0, 0);
+#pragma unroll
+        for (int f = 0; f < FC; ++f) a[f] = *reinterpret_cast<const u32x4*>(sw_ + swz_dma(wc * (BC / WC) + f * 16 + l16, 4 + g));
+#pragma unroll
+        for (int fa = 0; fa < FC; ++fa)
+#pragma unroll
+            for (int fb = 0; fb < FP; ++fb)
+                acc[fa][fb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bitcast<f16x8>(a[fa]), bitcast<f16x8>(bh[fb]), acc[fa][fb], 0, 0, 0);
+    };
+
     // ---- prime: strip 0 and weight slab 0 of the first tile
     setup_w(w_v);
     setup_s(s_v);
@@ -204,8 +236,8 @@ __global__ void __launch_bounds__(WC * WP * 64, WC * WP / 4) conv_strip_kernel(c
             asm volatile("" ::: "memory");
             issue_w_hot();
             if (s == 0) issue_s_hot();
-            compute_half(c_wst, c_sst, s, 0);
-            compute_half(c_wst, c_sst, s, 1);
+            if constexpr (X3) compute_x3(c_wst, c_sst, s);
+            else { compute_half(c_wst, c_sst, s, 0); compute_half(c_wst, c_sst, s, 1); }
             c_wst ^= 1;
             if (++s == 3) { s = 0; c_sst ^= 1; }
         }
@@ -217,22 +249,22 @@ __global__ void __launch_bounds__(WC * WP * 64, WC * WP / 4) conv_strip_kernel(c
             asm volatile("" ::: "memory");
             issue_w();
             if (t == 0) issue_s();
-            compute_half(c_wst, c_sst, t, 0);
-            compute_half(c_wst, c_sst, t, 1);
+            if constexpr (X3) compute_x3(c_wst, c_sst, t);
+            else { compute_half(c_wst, c_sst, t, 0); compute_half(c_wst, c_sst, t, 1); }
             c_wst ^= 1;
         }
         c_sst ^= 1;
         int co0, pix0;
         tile_coords(c_v, co0, pix0);
-        dma_epilogue<BC, BP, WC, WP, 16, 0, FC, FP>(p, acc, acc32_unused, co0, pix0, wc, wp, lane);
+        dma_epilogue<BC, BP, WC, WP, 16, 0, FC, FP, X3>(p, acc, acc32_unused, co0, pix0, wc, wp, lane);
     }
 }
 
-template <int BC, int BP, int WC, int WP>
+template <int BC, int BP, int WC, int WP, bool X3 = false>
 static int launch_strip_cfg(const ConvArgs& a, hipStream_t st) {
     constexpr int LDS = 2 * BC * 128 + 2 * StripCap<BP>::ROWS * 128;
     static_assert(LDS <= 160 * 1024, "LDS budget");
-    auto kern = conv_strip_kernel<BC, BP, WC, WP>;
+    auto kern = conv_strip_kernel<BC, BP, WC, WP, X3>;
     static thread_local DeviceOnce attr_once;      // per instantiation, per thread, per device
     if (!attr_once.done()) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
@@ -257,7 +289,8 @@ int conv_strip_pick(const ConvArgs& a, int dtype, bool explicit_request) {
     // 256x256 tiles: measured neutral (89.8 + 5.1 vs 94.5 ms per bench step; 128-VGPR budget of its 16 waves is exhausted,
     // 20 spills) — AUTO keeps the per-tap kernel there unless MNET_STRIP_256=1; the 64x512 tile (8 waves) gains 20 %.
     static const bool auto256 = [] { const char* e = getenv("MNET_STRIP_256"); return e && atoi(e) != 0; }();
-    if (dtype != MNET_F16 || !conv_dma_eligible(a, dtype)) return -1;      // (split-half launches take the per-tap LDS-DMA kernel)
+    if ((dtype != MNET_F16 && dtype != MNET_F16X2) || !conv_dma_eligible(a, dtype)) return -1;
+    if (dtype == MNET_F16X2 && a.cout >= 128) return -1;                   // split-half: the 64x512 tile only (the big tiles take the 8-wave per-tap forms)
     if (a.cout >= 256 && !explicit_request && !auto256) return -1;
     if (a.kh != 3 || a.kw != 3 || a.sh != 1 || a.sw != 1 || a.ph != 1 || a.pw != 1 || a.c1 != 0 || a.x1) return -1;
     if (a.ho != a.h || a.wo != a.w) return -1;
@@ -278,6 +311,10 @@ int conv_strip_pick(const ConvArgs& a, int dtype, bool explicit_request) {
 }
 
 int launch_conv_strip(const ConvArgs& a, hipStream_t st, int cfg) {
+    if (a.split) {
+        if (cfg == 1) return launch_strip_cfg<64, 512, 1, 8, true>(a, st);
+        return mnet_fail(MNET_E_ARG, "conv: strip configuration %d has no split-half form", cfg);
+    }
     if (cfg == 0) return launch_strip_cfg<256, 256, 4, 4>(a, st);
     if (cfg == 1) return launch_strip_cfg<64, 512, 1, 8>(a, st);
     if (cfg == 2) return launch_strip_cfg<128, 256, 2, 4>(a, st);

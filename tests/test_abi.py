@@ -85,11 +85,12 @@ def test_argument_validation_without_device():
     d2.cout = 256
     assert lib.mnet_conv2d_plan(ctypes.byref(d2), _lib.ALGO_AUTO) == _lib.ALGO_DMA_CFG0 + 11
     d2.cout = 64
-    assert lib.mnet_conv2d_plan(ctypes.byref(d2), _lib.ALGO_AUTO) == _lib.ALGO_DMA_CFG0 + 5
+    assert lib.mnet_conv2d_plan(ctypes.byref(d2), _lib.ALGO_AUTO) == _lib.ALGO_STRIP_CFG0 + 1      # strip kernel, split-half form
+    assert lib.mnet_conv2d_plan(ctypes.byref(d2), _lib.ALGO_DMA_CFG0 + 5) == _lib.ALGO_DMA_CFG0 + 5    # the per-tap 64x512 tile, pinned
     d2.c0 = 48
     assert lib.mnet_conv2d_plan(ctypes.byref(d2), _lib.ALGO_AUTO) == -2 and b"split-half" in lib.mnet_last_error()   # c0 % 32
     d2.c0 = 32
-    assert lib.mnet_conv2d_plan(ctypes.byref(d2), _lib.ALGO_AUTO) == _lib.ALGO_DMA_CFG0 + 5        # one 32-channel block per k-slab
+    assert lib.mnet_conv2d_plan(ctypes.byref(d2), _lib.ALGO_AUTO) == _lib.ALGO_STRIP_CFG0 + 1      # one 32-channel block per k-slab
     d2.x0 = 16
     assert lib.mnet_conv2d_plan(ctypes.byref(d2), _lib.ALGO_AUTO) == -2                             # 128-byte alignment
     d2.dtype = 1; d2.x0 = d2.wgt = d2.y = 16; d2.c0 = 64; d2.cout = 128

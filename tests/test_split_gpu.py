@@ -267,7 +267,8 @@ def _fuzz_cases():
         h, w = (rng.randint(100, 180), rng.randint(300, 420)) if big else (rng.randint(3, 40), rng.randint(8, 70))
         n = rng.randint(1, 2) if big else rng.randint(1, 9)
         cases.append((n, h, w, cin - c1, c1, cout, k, stride))
-    cases += [(4, 64, 64, 64, 0, 256, 3, (1, 1)), (2, 128, 128, 128, 0, 64, 3, (1, 1)), (300, 16, 16, 64, 0, 128, 3, (1, 1))]   # >= 65536 pixels: the big tiles
+    cases += [(4, 64, 64, 64, 0, 256, 3, (1, 1)), (2, 128, 128, 128, 0, 64, 3, (1, 1)), (300, 16, 16, 64, 0, 128, 3, (1, 1)),   # >= 65536 pixels: the big tiles
+              (4, 128, 128, 64, 0, 64, 3, (1, 1)), (1, 32, 2048, 96, 0, 64, 3, (1, 1)), (64, 32, 32, 32, 0, 96, 3, (1, 1))]       # strip kernel (cout < 128)
     return cases
 
 
@@ -296,6 +297,8 @@ def test_conv_fuzz_all_paths_agree(case):
     if cout >= 64 and (c0 + c1) % 32 == 0:
         y_one = ops.conv2d(x0, wp, cout, k, k, stride, (pad, pad), algo=_lib.ALGO_LDS_DMA | _lib.ALGO_FLAG_ONE_TILE, **kw)
         assert torch.equal(y_auto.view(torch.float16), y_one.view(torch.float16))
+        y_tap = ops.conv2d(x0, wp, cout, k, k, stride, (pad, pad), algo=_lib.ALGO_DMA_CFG0 + 3, **kw)      # a pinned per-tap tile
+        assert torch.equal(y_auto.view(torch.float16), y_tap.view(torch.float16))                          # (AUTO may be the strip kernel)
     torch.cuda.synchronize()
     assert float((a - r).abs().max()) <= 4e-6 * float(r.abs().max())
     xs = xa[:1].clone()
