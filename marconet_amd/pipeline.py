@@ -109,8 +109,11 @@ class MarconetPipeline:
         return y if return_nhwc else ops.nhwc_to_nchw(y, c=3)
 
 
-    @torch.no_grad()
     def forward_mixed_widths(self, lq, content_widths, labels, locs, bucket=64):
+        with torch.no_grad(), ops.on_device(lq):
+            return self._forward_mixed_widths(lq, content_widths, labels, locs, bucket)
+
+    def _forward_mixed_widths(self, lq, content_widths, labels, locs, bucket):
         """BASELINE configs[4]: a batch of strips of different content widths (each zero-padded to 512, i.e. -1 after
         Normalize, test_sr.py:100-115).  The encoder needs the 512-wide strip (its token-axis LayerNorm(64)/Linear(64,.)
         pin 64 tokens, models/textvit_arch.py:59-62,141-144); TSPSRNet is width-agnostic, so images are bucketed by
@@ -227,7 +230,8 @@ def clear_labels_batch(logits):
     ONE device→host copy of the [B,64] indices, then the CTC-style collapse on the host (drop repeats, drop blanks).
     → list of B int64 tensors [n_b, 1] (CPU)."""
     B, T, C = logits.shape
-    idx = ops.argmax_rows(logits.reshape(B * T, C).contiguous().float()).reshape(B, T).cpu().tolist()
+    with ops.on_device(logits):
+        idx = ops.argmax_rows(logits.reshape(B * T, C).contiguous().float()).reshape(B, T).cpu().tolist()
     return [torch.tensor(collapse_indices(row), dtype=torch.int64).reshape(-1, 1) for row in idx]
 
 
@@ -276,15 +280,16 @@ class GraphedForward:
         self.widths = (self.lq.shape[3], 2 * self.lq.shape[3])           # feature widths at the 32- and 64-row scales
         self.tables = (GlyphTables(dummy, self.counts, self.widths[0], 16, dev),
                        GlyphTables(dummy, self.counts, self.widths[1], 32, dev)) if G else None
-        side = torch.cuda.Stream(device=dev)
-        side.wait_stream(torch.cuda.current_stream(dev))
-        with torch.cuda.stream(side):                                  # warm-up: packs weights, raises kernel attributes
-            for _ in range(2):
-                pipe._core(self.lq, self.lab, self.img_of, self.counts, None, self.tables, output=output)
-        torch.cuda.current_stream(dev).wait_stream(side)
-        self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph):
-            self.out = pipe._core(self.lq, self.lab, self.img_of, self.counts, None, self.tables, output=output)
+        with ops.on_device(self.lq):
+            side = torch.cuda.Stream(device=dev)
+            side.wait_stream(torch.cuda.current_stream(dev))
+            with torch.cuda.stream(side):                              # warm-up: packs weights, raises kernel attributes
+                for _ in range(2):
+                    pipe._core(self.lq, self.lab, self.img_of, self.counts, None, self.tables, output=output)
+            torch.cuda.current_stream(dev).wait_stream(side)
+            self.graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self.graph):
+                self.out = pipe._core(self.lq, self.lab, self.img_of, self.counts, None, self.tables, output=output)
 
     @torch.no_grad()
     def __call__(self, lq, labels, locs):
