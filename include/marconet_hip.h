@@ -251,6 +251,12 @@ int mnet_embed_gather(const float* emb, const int64_t* labels, void* out, int32_
 int mnet_demod(const float* style, const float* wsq_t, float* demod, int32_t N, int32_t cin,
                int32_t cout, void* stream);
 
+/* mnet_demod with eps scaled per sample: demod[n,o] = rsqrt( sum_i style[n,i]^2 wsq_t[i,o] + 1e-8 * eps_scale[n] ) — for style rows that
+ * mnet_style_rows normalised by 2^-e (eps_scale = 4^-e): the result is then exactly 2^e times mnet_demod of the original row.
+ * eps_scale == NULL: mnet_demod. */
+int mnet_demod_scaled(const float* style, const float* wsq_t, float* demod, int32_t N, int32_t cin, int32_t cout,
+                      const float* eps_scale, void* stream);
+
 /* argmax over the last dim (first maximal index, like torch.max(...,1)[1] in test_w.py:36) */
 int mnet_argmax_rows(const float* x, int64_t* idx, int32_t rows, int32_t d, void* stream);
 
@@ -296,6 +302,14 @@ int mnet_pack_weights(const float* w_oihw, int32_t cout, int32_t cin, int32_t kh
 /* demodulation table of a ModulatedConv2d for activation-side modulation (input of mnet_demod):
  *   wsq_t[i][o] = sum_{r,s} (scale * w[o][i][r][s])^2,  fp32 [cin][cout]   (networks.py:284-287) */
 int mnet_pack_wsq(const float* w_oihw, int32_t cout, int32_t cin, int32_t khw, float scale, float* wsq_t, void* stream);
+
+/* mnet_gather_rows with every output row divided by 2^e, e = exponent of the row window's largest magnitude (max * 2^-e in [0.5, 1)):
+ * the style rows of a modulated conv, normalised so that the modulated activations x * s stay below |x| in the half-precision
+ * storage modes (ModulatedConv2d's s can be large with trained weights; models/networks.py:283-287).  Exact (power-of-two factors):
+ * eps_scale[r] = 4^-e goes to mnet_demod_scaled, scale_b[r][0..bcast) = 2^e is the out_scale of a conv without demodulation (ToRGB,
+ * networks.py:305-321).  eps_scale / scale_b may be NULL. */
+int mnet_style_rows(const float* src, int32_t src_rows, int32_t ld, int32_t col0, int32_t ncols, const int64_t* idx,
+                    int32_t rows, float* dst, float* eps_scale, float* scale_b, int32_t bcast, void* stream);
 
 /* dst[r][0..ncols) = src[idx ? idx[r] : r][col0 .. col0+ncols)  (fp32; src [src_rows][ld]; idx int64 [rows] or NULL): every glyph
  * takes its image's row of the per-style tensors (test_sr.py:183 gives all glyphs of a strip the same w), every StyledConv its

@@ -78,6 +78,8 @@ SYMBOLS = {
     "mnet_pack_weights": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_float, c_int, c_int, c_int, c_void_p,
                                   c_void_p, c_void_p]),
     "mnet_pack_wsq": (c_int, [c_void_p, c_int, c_int, c_int, c_float, c_void_p, c_void_p]),
+    "mnet_demod_scaled": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
+    "mnet_style_rows": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
     "mnet_gather_rows": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_int, c_void_p, c_void_p]),
 }
 

@@ -709,7 +709,7 @@ extern "C" int mnet_pixelnorm(const float* x, float* y, int32_t N_, int32_t D, v
 // grid (cout/64, styles): a workgroup owns 64 output channels of one style; its 4 waves each sum one quarter of cin (the loop
 // is a chain of exposed load latencies — 16 loads are kept in flight per lane), folded in fixed order through LDS.
 __global__ void __launch_bounds__(256) demod_kernel(const float* __restrict__ style, const float* __restrict__ wsq_t,
-                                                    float* __restrict__ demod, int cin, int cout) {
+                                                    float* __restrict__ demod, int cin, int cout, const float* __restrict__ eps_scale) {
     extern __shared__ __attribute__((aligned(16))) unsigned char dyn[];
     float* s2 = reinterpret_cast<float*>(dyn);                  // [cin] squared style
     __shared__ float part[4][64];
@@ -731,16 +731,23 @@ __global__ void __launch_bounds__(256) demod_kernel(const float* __restrict__ st
     for (; i < i1; ++i) acc = fmaf(s2[i], wp[(size_t)i * cout], acc);
     part[q][lane] = acc;
     __syncthreads();
-    if (q == 0 && o < cout) demod[(size_t)n * cout + o] = rsqrtf(((part[0][lane] + part[1][lane]) + (part[2][lane] + part[3][lane])) + 1e-8f);
+    // eps_scale[n] = 4^-e when the style row was normalised by 2^-e (mnet_style_rows): rsqrt(4^-e (S + 1e-8)) = 2^e rsqrt(S + 1e-8), exactly
+    const float eps = eps_scale ? 1e-8f * eps_scale[n] : 1e-8f;
+    if (q == 0 && o < cout) demod[(size_t)n * cout + o] = rsqrtf(((part[0][lane] + part[1][lane]) + (part[2][lane] + part[3][lane])) + eps);
+}
+
+extern "C" int mnet_demod_scaled(const float* style, const float* wsq_t, float* demod, int32_t N_, int32_t cin,
+                                 int32_t cout, const float* eps_scale, void* stream) {
+    MNET_CHECK_ARG(style && wsq_t && demod && N_ > 0 && cin > 0 && cout > 0 && N_ <= 65535, "demod: bad args");
+    hipLaunchKernelGGL(demod_kernel, dim3((cout + 63) / 64, N_), dim3(256), (size_t)cin * sizeof(float), reinterpret_cast<hipStream_t>(stream),
+                       style, wsq_t, demod, cin, cout, eps_scale);
+    MNET_LAUNCH_CHECK("demod");
+    return MNET_OK;
 }
 
 extern "C" int mnet_demod(const float* style, const float* wsq_t, float* demod, int32_t N_, int32_t cin,
                           int32_t cout, void* stream) {
-    MNET_CHECK_ARG(style && wsq_t && demod && N_ > 0 && cin > 0 && cout > 0 && N_ <= 65535, "demod: bad args");
-    hipLaunchKernelGGL(demod_kernel, dim3((cout + 63) / 64, N_), dim3(256), (size_t)cin * sizeof(float), reinterpret_cast<hipStream_t>(stream),
-                       style, wsq_t, demod, cin, cout);
-    MNET_LAUNCH_CHECK("demod");
-    return MNET_OK;
+    return mnet_demod_scaled(style, wsq_t, demod, N_, cin, cout, nullptr, stream);
 }
 
 // ============================================================================ dtype conversion (flat)

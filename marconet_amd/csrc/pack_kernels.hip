@@ -119,6 +119,43 @@ __global__ void __launch_bounds__(256) gather_rows_kernel(const float* __restric
     }
 }
 
+// ---------------------------------------------------------------------------- style rows, normalised by a power of two
+// dst[r][:] = src[idx ? idx[r] : r][col0 .. col0+ncols) * 2^-e[r],  e[r] = exponent of max|row window| (max * 2^-e in [0.5, 1); e = 0 for
+// an all-zero row).  The modulated activations x * s are then bounded by |x| whatever the style's magnitude — the half-precision
+// hazard of StyleGAN-type generators — and nothing else changes: the demodulation rsqrt(sum (W s)^2 + eps) absorbs the factor
+// exactly when its eps is scaled by 4^-e (eps_scale), a conv without demodulation (ToRGB) multiplies its accumulator by 2^e
+// (scale_b, broadcast over `bcast` output channels so that it can be passed as out_scale [rows][bcast]).  Power-of-two factors:
+// every fp32 product and sum is scaled exactly, results are bit-identical to the un-normalised evaluation.
+__global__ void __launch_bounds__(256) style_rows_kernel(const float* __restrict__ src, int ld, int col0, int ncols,
+                                                         const int64_t* __restrict__ idx, float* __restrict__ dst,
+                                                         float* __restrict__ eps_scale, float* __restrict__ scale_b, int bcast) {
+    __shared__ float red[4];
+    const int r = blockIdx.x, t = threadIdx.x;
+    const float* row = src + (size_t)(idx ? idx[r] : r) * ld + col0;
+    float m = 0.f;
+    for (int c = t; c < ncols; c += 256) m = fmaxf(m, fabsf(row[c]));
+    m = wave_max(m);
+    if ((t & 63) == 0) red[t >> 6] = m;
+    __syncthreads();
+    m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    int e = 0;
+    if (m > 0.f && m < INFINITY) (void)frexpf(m, &e);
+    const float down = ldexpf(1.f, -e), up = ldexpf(1.f, e);
+    for (int c = t; c < ncols; c += 256) dst[(size_t)r * ncols + c] = row[c] * down;
+    if (t == 0 && eps_scale) eps_scale[r] = down * down;
+    if (scale_b) for (int c = t; c < bcast; c += 256) scale_b[(size_t)r * bcast + c] = up;
+}
+
+extern "C" int mnet_style_rows(const float* src, int32_t src_rows, int32_t ld, int32_t col0, int32_t ncols, const int64_t* idx,
+                               int32_t rows, float* dst, float* eps_scale, float* scale_b, int32_t bcast, void* stream) {
+    MNET_CHECK_ARG(src && dst && src_rows > 0 && rows > 0 && ncols > 0 && col0 >= 0 && col0 + ncols <= ld, "style_rows: bad args");
+    MNET_CHECK_ARG(!scale_b || bcast > 0, "style_rows: bcast must be positive with scale_b");
+    hipLaunchKernelGGL(style_rows_kernel, dim3(rows), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), src, ld, col0, ncols, idx, dst,
+                       eps_scale, scale_b, bcast);
+    MNET_LAUNCH_CHECK("style_rows");
+    return MNET_OK;
+}
+
 extern "C" int mnet_gather_rows(const float* src, int32_t src_rows, int32_t ld, int32_t col0, int32_t ncols, const int64_t* idx,
                                 int32_t rows, float* dst, void* stream) {
     MNET_CHECK_ARG(src && dst && src_rows > 0 && rows > 0 && ncols > 0 && col0 >= 0 && col0 + ncols <= ld, "gather_rows: bad args");

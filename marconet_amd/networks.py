@@ -10,6 +10,7 @@ repacked once per load, the modulated conv is applied on the activation side, an
 loops become batched kernels over all glyphs of the batch.  The child ``nn.Module``s hold parameters only.
 """
 import math
+import os
 
 import torch
 import torch.nn as nn
@@ -21,6 +22,7 @@ from .packing import (PRECISIONS, SPLIT_DTYPE, PackCache, default_precision, equ
 from .resnet import resnet45stride as resnet45
 from .textvit_arch import TextViT as TextEncoder
 
+_STYLE_NORM = not bool(int(os.environ.get("MNET_NO_STYLE_NORM", "0")))     # A/B knob (tests): style rows normalised by a power of two
 RGB_PAD = 8      # 3-channel tensors are carried with 8 channels (one 16-byte fp16 chunk); 32 in the split-half mode (rgb_pad)
 
 
@@ -197,18 +199,23 @@ class TextGenerator(nn.Module):
         return pk
 
     # ------------------------------------------------------------------ forward pieces
-    def _mod(self, L):
-        """this layer's column window of the batched modulation EqualLinear (:283), one row per glyph (mnet_gather_rows: the
-        window and — with distinct styles — the glyph → style row gather in one small launch)"""
-        return ops.gather_rows(self._S, L["mod_off"], L["cin"], self._gidx)
+    def _mod(self, L, idx, bcast=0):
+        """this layer's column window of the batched modulation EqualLinear (:283), one row per entry of ``idx`` (None: per style)
+        → (rows, eps_scale, scale_b).  The rows are divided by 2^e (largest magnitude in [0.5, 1): mnet_style_rows), so the modulated
+        activations x·s never exceed |x| in the half-precision storage modes; eps_scale = 4^-e makes the demodulation absorb the
+        factor exactly, scale_b = 2^e [rows, bcast] undoes it for a conv without demodulation (ToRGB).  Power-of-two factors:
+        bit-identical to the un-normalised evaluation (tests/test_modules_gpu.py::test_style_normalisation_is_exact)."""
+        if _STYLE_NORM:
+            return ops.style_rows(self._S, L["mod_off"], L["cin"], idx, bcast)
+        return ops.gather_rows(self._S, L["mod_off"], L["cin"], idx), None, None
 
     def _style(self, L):
         """→ (modulation rows per glyph, demodulation table rsqrt(Σ (scale·W·s)² + 1e-8) per glyph (:286))"""
-        s = self._mod(L)
+        s, eps, _ = self._mod(L, self._gidx)
         if self._gidx is None:
-            return s, ops.demod(s, L["wsq_t"])
-        su = ops.gather_rows(self._S, L["mod_off"], L["cin"])       # demodulation once per distinct style, gathered per glyph
-        return s, ops.gather_rows(ops.demod(su, L["wsq_t"]), idx=self._gidx)
+            return s, ops.demod(s, L["wsq_t"], eps)
+        su, eps_u, _ = self._mod(L, None)                           # demodulation once per distinct style, gathered per glyph
+        return s, ops.gather_rows(ops.demod(su, L["wsq_t"], eps_u), idx=self._gidx)
 
     @staticmethod
     def _styled(L, x, s, d, premodulated, post=None, out=None):
@@ -219,10 +226,10 @@ class TextGenerator(nn.Module):
                           out_scale=d, bias=L["bias"], act=ops.ACT_LRELU_SQRT2, post_scale=post, out=out)
 
     def _to_rgb(self, L, x, skip):
-        s = self._mod(L)
+        s, _, sb = self._mod(L, self._gidx, bcast=L["w"].shape[0])
         if skip is not None:
             skip = ops.upsample2x(skip)                                        # :318-319
-        return ops.conv2d(x, L["w"], L["w"].shape[0], in_scale=s, bias=L["bias"], residual=skip, act=ops.ACT_TANH)
+        return ops.conv2d(x, L["w"], L["w"].shape[0], in_scale=s, out_scale=sb, bias=L["bias"], residual=skip, act=ops.ACT_TANH)
 
     def forward_nhwc(self, styles, labels, need_image=True, style_index=None, p64_out=None, p32_out=None):
         """→ (image NHWC [N,128,128c,8], prior64 NHWC [N,64,64c,256], prior32 NHWC [N,32,32c,512]).

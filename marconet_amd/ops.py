@@ -17,7 +17,7 @@ from .packing import SPLIT_DTYPE
 __all__ = ["conv2d", "linear", "nchw_to_nhwc", "nhwc_to_nchw", "upsample2x", "affine_act", "groupnorm_affine",
            "adain_crop_concat", "adain_crop_concat_gn", "glyph_scatter_affine", "layernorm", "token_mix", "attention", "pixelnorm",
            "embed_gather", "demod", "argmax_rows", "convert", "fused_bias_act", "sr_postprocess", "conv3x3_rgb", "stats",
-           "pack_weights", "pack_wsq", "gather_rows",
+           "pack_weights", "pack_wsq", "gather_rows", "style_rows",
            "ACT_NONE", "ACT_RELU", "ACT_LRELU", "ACT_LRELU_SQRT2", "ACT_TANH", "ACT_GELU", "ACT_SIGMOID"]
 
 
@@ -342,14 +342,32 @@ def embed_gather(emb, labels, dtype, num_classes):
     return out
 
 
-def demod(style, wsq_t):
+def demod(style, wsq_t, eps_scale=None):
+    """rsqrt(Σ_i style² wsq_t + 1e-8·eps_scale[n]) — eps_scale (fp32 [N], 4^-e) for rows normalised by ``style_rows``"""
     lib = _lib.load()
-    _need_cuda(style, wsq_t)
+    _need_cuda(style, wsq_t, eps_scale)
     N, cin = style.shape
     cout = wsq_t.shape[1]
     out = torch.empty((N, cout), dtype=torch.float32, device=style.device)
-    _lib.check(lib.mnet_demod(_p(style), _p(wsq_t), _p(out), N, cin, cout, _stream()), "mnet_demod")
+    _lib.check(lib.mnet_demod_scaled(_p(style), _p(wsq_t), _p(out), N, cin, cout, _p(eps_scale), _stream()), "mnet_demod_scaled")
     return out
+
+
+def style_rows(src, col0, ncols, idx=None, bcast=0):
+    """mnet_style_rows: window + row gather of the modulation GEMM's output with every row divided by 2^e (largest magnitude in
+    [0.5, 1)) → (rows [R,ncols], eps_scale [R] = 4^-e, scale_b [R,bcast] = 2^e or None)"""
+    lib = _lib.load()
+    _need_cuda(src, idx)
+    if src.dtype != torch.float32 or src.dim() != 2 or (idx is not None and idx.dtype != torch.int64):
+        raise TypeError("style_rows: fp32 [rows, ld] source and int64 indices expected")
+    rows = src.shape[0] if idx is None else idx.shape[0]
+    dst = torch.empty((rows, ncols), dtype=torch.float32, device=src.device)
+    eps = torch.empty((rows,), dtype=torch.float32, device=src.device)
+    sb = torch.empty((rows, bcast), dtype=torch.float32, device=src.device) if bcast else None
+    if rows:
+        _lib.check(lib.mnet_style_rows(_p(src), src.shape[0], src.shape[1], col0, ncols, _p(idx), rows, _p(dst), _p(eps), _p(sb), bcast,
+                                       _stream()), "mnet_style_rows")
+    return dst, eps, sb
 
 
 def argmax_rows(x):

@@ -134,6 +134,9 @@ def test_argument_validation_without_device():
     assert lib.mnet_pack_weights(16, 8, 8, 3, 3, None, None, 1.0, 1, 4, 8, 128, None, None) == -1            # cout_pad < cout
     assert lib.mnet_pack_wsq(None, 8, 8, 9, 1.0, 16, None) == -1
     assert lib.mnet_gather_rows(16, 4, 8, 6, 4, None, 4, 16, None) == -1                                       # window beyond ld
+    assert lib.mnet_style_rows(16, 4, 8, 6, 4, None, 4, 16, None, None, 0, None) == -1                          # window beyond ld
+    assert lib.mnet_style_rows(16, 4, 8, 0, 4, None, 4, 16, None, 16, 0, None) == -1 and b"bcast" in lib.mnet_last_error()
+    assert lib.mnet_demod_scaled(None, 16, 16, 1, 8, 8, None, None) == -1
     assert lib.mnet_convert(128, 0, 256, 2, 24, None) == -2 and b"split-half" in lib.mnet_last_error()        # count % 32
 
 

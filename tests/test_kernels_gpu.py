@@ -668,3 +668,26 @@ def test_pack_wsq_linear_and_gather_rows():
     assert torch.equal(ops.gather_rows(src.to(DEV), 5, 20, idx.to(DEV)).cpu(), src[idx][:, 5:25])
     assert torch.equal(ops.gather_rows(src.to(DEV), 8, 32).cpu(), src[:, 8:40])
     assert torch.equal(ops.gather_rows(src.to(DEV), idx=idx.to(DEV)).cpu(), src[idx])
+
+
+def test_style_rows_and_scaled_demod():
+    """mnet_style_rows (row window + gather + power-of-two normalisation) and mnet_demod_scaled: the normalised evaluation equals the
+    plain one exactly — demod' = 2^e demod, rows' = 2^-e rows"""
+    ops = _ops()
+    src = _rnd((7, 96), 221) * torch.tensor([1e-3, 1.0, 37.0, 4e4, 0.0, 0.26, 1.0]).reshape(7, 1)     # row 4: all zeros
+    idx = torch.tensor([3, 3, 0, 6, 4, 2, 1, 5], dtype=torch.int64)
+    rows, eps, sb = ops.style_rows(src.to(DEV), 16, 64, idx.to(DEV), bcast=8)
+    plain = src[idx][:, 16:80]
+    m = plain.abs().amax(dim=1)
+    e = torch.where(m > 0, torch.frexp(m).exponent.float(), torch.zeros_like(m))
+    assert torch.equal(rows.cpu(), plain * torch.exp2(-e)[:, None])
+    assert torch.equal(eps.cpu(), torch.exp2(-2 * e)) and torch.equal(sb.cpu(), torch.exp2(e)[:, None].expand(8, 8))
+    nz = m > 0
+    assert bool(((rows.cpu().abs().amax(dim=1)[nz] >= 0.5) & (rows.cpu().abs().amax(dim=1)[nz] < 1.0)).all())
+    wsq = _rnd((64, 40), 222).abs() * 0.01
+    d0 = ops.demod(plain.contiguous().to(DEV), wsq.to(DEV))
+    d1 = ops.demod(rows, wsq.to(DEV), eps)
+    want = d0.cpu() * torch.exp2(e)[:, None]
+    assert float(((d1.cpu() - want).abs() / want).max()) <= 2e-7                     # rsqrt of an argument scaled by 4^-e
+    r2, eps2, none = ops.style_rows(src.to(DEV), 0, 96)
+    assert none is None and r2.shape == (7, 96) and float(r2[4].abs().max()) == 0.0 and float(eps2[4]) == 1.0

@@ -274,6 +274,40 @@ def test_fp16x3_mixed_widths_and_reference_call_form(nets, ckpts):
         pipe.set_precision("fp32")
 
 
+def test_style_normalisation_is_exact_and_removes_the_half_precision_hazard(nets, ckpts):
+    """The generator normalises every style row by a power of two (mnet_style_rows) and lets the demodulation / ToRGB scale absorb it.
+    (1) fp32: bit-identical to the un-normalised evaluation; (2) with modulation weights 3e4 times larger — styles no half can
+    carry once multiplied into an activation — the fp16x3 priors still match the CPU oracle, while the un-normalised path overflows."""
+    from marconet_amd import networks
+    styles, labels = synth.make_styles(191, 3), synth.make_labels(192, 3)
+    gan = nets[1]
+    try:
+        a = gan(styles=styles.to(DEV), labels=labels.to(DEV), noise=None)
+        networks._STYLE_NORM = False
+        b = gan(styles=styles.to(DEV), labels=labels.to(DEV), noise=None)
+        networks._STYLE_NORM = True
+        for x, y in zip(a, b):
+            assert torch.equal(x, y)
+        big = {k: (v * 3e4 if ".modulation." in k else v) for k, v in ckpts[1].items()}
+        g2 = networks.TSPGAN()
+        g2.load_state_dict(big, strict=True)
+        g2 = g2.eval().to(DEV).set_precision("fp16x3")
+        with torch.no_grad():
+            ref = O.tspgan_forward(big, styles, labels)
+        out = g2(styles=styles.to(DEV), labels=labels.to(DEV), noise=None)
+        assert all(bool(torch.isfinite(t).all()) for t in out)
+        e64, e32 = _err(out[1], ref[1]), _err(out[2], ref[2])
+        _note("gan.fp16x3.big_styles.prior64.maxabs", e64)
+        assert e64 <= TOL and e32 <= TOL          # (the image is tanh(3e4 * ...): saturated, its zero crossings amplify any rounding — not compared)
+        networks._STYLE_NORM = False
+        bad = g2(styles=styles.to(DEV), labels=labels.to(DEV), noise=None)
+        networks._STYLE_NORM = True
+        # x * s leaves the half range without the normalisation: non-finite values, or (where a saturated value meets a zero) plain wrong ones
+        assert (not bool(torch.isfinite(bad[1]).all())) or _err(bad[1], ref[1]) > 100 * TOL
+    finally:
+        networks._STYLE_NORM = True
+
+
 def test_error_behaviour(nets):
     """errors surface as Python exceptions so test_sr.py's try/except…continue (:181-190) keeps working"""
     styles = synth.make_styles(1, 2).to(DEV)
