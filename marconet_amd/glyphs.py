@@ -26,7 +26,9 @@ class GlyphTables:
     Vectorised (numpy) over all glyphs of the batch — at 64 images x 16 glyphs the per-glyph Python loop cost ~60 ms of
     host time per forward; ``window`` above stays the scalar statement of the same arithmetic (and is what the tests pin)."""
 
-    def __init__(self, locs_host, counts, feat_w, half, device):
+    def __init__(self, locs_host, counts, feat_w, half, device, centre_w=None):
+        """``centre_w`` (mixed-width bucketing): the feature width the centres are computed at — the width of the 512-padded run the
+        locs were normalised for — while windows are clipped to this map's ``feat_w``; default: feat_w (the reference's arithmetic)"""
         counts = np.asarray(counts, dtype=np.int64)
         B = counts.shape[0]
         if B and int(counts.max(initial=0)) * 2 > locs_host.shape[1]:
@@ -36,7 +38,7 @@ class GlyphTables:
         g_start = np.concatenate([[0], np.cumsum(counts)])
         c_idx = np.arange(g_img.shape[0], dtype=np.int64) - g_start[g_img]                    # glyph index inside its image
         loc = np.asarray(locs_host, dtype=np.float32)[g_img, 2 * c_idx] if g_img.size else np.zeros((0,), np.float32)
-        center = (loc * np.float32(feat_w)).astype(np.int32)                                  # fp32 product, truncation toward zero
+        center = (loc * np.float32(feat_w if centre_w is None else centre_w)).astype(np.int32)   # fp32 product, truncation toward zero
         x1 = np.where(center < half, 0, center - half)
         x2 = np.where(center + half > feat_w, feat_w, center + half)
         gw = x2 - x1

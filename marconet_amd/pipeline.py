@@ -11,6 +11,7 @@ collective and no weight traffic.
 import torch
 
 from . import ops
+from .glyphs import GlyphTables
 from .packing import default_precision, torch_dtype
 
 
@@ -152,13 +153,17 @@ class MarconetPipeline:
             cb = [counts[b] for b in idx]
             it = torch.tensor(idx, device=dev)
             lq_b = lq.index_select(0, it)[:, :, :, :wb].contiguous()
-            locs_b = (locs.to(dev).index_select(0, it).float() * (512.0 / wb)).contiguous()
+            # glyph centres as in the 512-padded run the locs were normalised for (trunc(loc * 512) / trunc(loc * 1024): integer tables
+            # from the ORIGINAL locs — re-normalising to the bucket width in fp32 can move a centre by one pixel), windows clipped to
+            # the bucket's width
+            lh = locs.detach().float().cpu().numpy()[idx]
+            tables = (GlyphTables(lh, cb, wb, 16, dev, centre_w=512), GlyphTables(lh, cb, 2 * wb, 32, dev, centre_w=1024)) if gsel else None
             if gsel:
                 gt = torch.tensor(gsel, device=dev)
                 a, c = ops.take_rows(p64, gt), ops.take_rows(p32, gt)
             else:
                 a = c = None
-            y = self.sr.forward_packed(lq_b, a, c, cb, cb, locs_b, nchw_out=True)
+            y = self.sr.forward_packed(lq_b, a, c, cb, cb, None, nchw_out=True, tables=tables)
             for k, b in enumerate(idx):
                 out[b] = y[k]
         return out

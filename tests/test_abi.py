@@ -237,6 +237,15 @@ def test_graph_path_host_pieces():
     assert all(torch.equal(getattr(static, n), getattr(fresh, n)) for n in ("g_img", "g_x1", "g_y1", "g_w", "g_start"))
     with pytest.raises(ValueError):
         GlyphTables(locs, [3, 1, 2], 512, 16, "cpu").copy_into(static)
+    # mixed-width bucketing: centres as in the 512-padded run (centre_w), windows clipped to the bucket width
+    rng = np.random.default_rng(11)
+    lh = (rng.random((4, 8)) * (180.0 / 512.0)).astype(np.float32)            # all centres left of 180 px
+    full = GlyphTables(lh, [4, 4, 4, 4], 512, 16, "cpu")
+    buck = GlyphTables(lh, [4, 4, 4, 4], 192, 16, "cpu", centre_w=512)
+    assert torch.equal(full.g_x1, buck.g_x1) and torch.equal(full.g_y1[full.g_x1 + 32 <= 192], buck.g_y1[full.g_x1 + 32 <= 192])
+    assert int((buck.g_x1 + buck.g_w).max()) <= 192
+    renorm = GlyphTables((lh * np.float32(512.0 / 192.0)).astype(np.float32), [4, 4, 4, 4], 192, 16, "cpu")     # the fp32 re-normalisation it replaces
+    assert int((renorm.g_x1 - buck.g_x1).abs().max()) <= 1
     pipe = MarconetPipeline(networks.TextContextEncoderV2(), networks.TSPGAN(), networks.TSPSRNet())
     lab, img_of = pipe._host_prep([torch.tensor([5, 6, 7]), torch.zeros(0, dtype=torch.long), torch.tensor([1, 2])], counts, "cpu")
     assert lab.shape == (5, 1) and img_of.tolist() == [0, 0, 0, 2, 2]
