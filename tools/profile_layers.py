@@ -60,7 +60,7 @@ def main():
         ms = s.elapsed_time(e)
         tot_conv += ms
         lines.append("%-4s n=%-5d %4dx%-4d c=%3d+%-3d -> %4d k%d s%s out %4dx%-4d %s%s%s%s%s act%d k%-2d %8.3f ms %8.1f TF/s %5.1f%%"
-                     % ("f16" if r["dt"] else "f32", r["n"], r["h"], r["w"], r["c0"], r["c1"], r["cout"], r["k"], r["s"], r["ho"], r["wo"],
+                     % ({0: "f32", 1: "f16", 2: "x3 "}[r["dt"]], r["n"], r["h"], r["w"], r["c0"], r["c1"], r["cout"], r["k"], r["s"], r["ho"], r["wo"],
                         "P" if r["pro"] else "-", "S" if r["sw"] else "-", "V" if r["vw"] else "-", "D" if r["osc"] else "-",
                         "R" if r["res"] else "-", r["act"], kid, ms, fl / ms / 1e9, 100 * ms / total))
     lines.append("step total %.2f ms, conv launches %.2f ms (%d), other %.2f ms" % (total, tot_conv, len(recs), total - tot_conv))
