@@ -46,6 +46,7 @@ KNAME = {1: "conv_igemm_kernel (register-staged)", 3: "conv_skinny_f32_kernel", 
          18: "conv_dma_kernel<128,256,2,4,3,16>", 19: "conv_dma_kernel<64,256,1,8,3,16>", 20: "conv_dma_kernel<128,512,2,8,2,16>",
          21: "conv_dma_kernel<64,512,1,8,2,16>", 22: "conv_dma_kernel<256,256,2,4,2,16>", 26: "conv_dma_kernel<128,128,2,4,4,16>",
          24: "conv_dma_kernel<256,256,4,4,2,16,spread>", 25: "conv_dma_kernel<128,512,2,8,2,16,spread>",
+         64: "conv_dma_kernel<256,256,2,4,2,16,spread,pipe>", 65: "conv_dma_kernel<128,512,2,4,2,16,spread,pipe>",
          32: "conv_strip_kernel<256,256,4,4>", 33: "conv_strip_kernel<64,512,1,8>", 34: "conv_strip_kernel<128,256,2,4>"}
 KNAME_X3 = {33: "conv_strip_kernel<64,512,1,8,x3>", 22: "conv_dma_kernel<256,256,2,4,2,16>", 23: "conv_dma_kernel<128,512,2,4,2,16>",      # split-half ids 6 / 7: the 8-wave tiles
             24: "conv_dma_kernel<256,256,2,4,2,16,spread>", 25: "conv_dma_kernel<128,512,2,4,2,16,spread>",

@@ -125,6 +125,11 @@ enum { MNET_CONV_ALGO_AUTO = 0, MNET_CONV_ALGO_REG_STAGED = 1, MNET_CONV_ALGO_LD
                                         * three taps; id 0: 256x256 tile, id 1: 64x512 tile).  Eligible: 3x3/stride 1/pad 1, one
                                         * source, cout >= 256 (id 0) or < 128 (id 1), >= 65536 output pixels, whole-row tiles.
                                         * AUTO uses id 1 when eligible (id 0 measured neutral: explicit request only; MNET_F16X2: id 1 only).  Same k order and MFMA as the LDS-DMA kernel → identical bits. */,
+       MNET_CONV_ALGO_DMA_CFG16 = 64 /* + (id - 16): LDS-DMA tile configurations 16.. (the ids 0..15 above are full):
+                                       *   id 16: 256x256 8w 2st (128x64 per wave) with both half slabs' operand fragments requested up front and the
+                                       *          next slab's DMA pieces issued between the halves — AUTO's f16 choice for cout >= 256, >= 65536 pixels
+                                       *   id 17: the same form of the 128x512 tile (64x128 per wave)
+                                       * same MFMA sequence as ids 0-6: identical bits */,
        MNET_CONV_ALGO_FLAG_ONE_TILE = 256 /* OR-ed in: LDS-DMA kernel launched with one workgroup per tile instead of its
                                             * persistent grid (A/B measurements only; same results) */ };
 int mnet_conv2d_nhwc_ex(const mnet_conv_desc* d, int32_t algo, void* stream);

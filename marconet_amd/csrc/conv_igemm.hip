@@ -422,7 +422,8 @@ static int conv_prepare(const mnet_conv_desc* d, int32_t algo, ConvArgs& a) {
     a.one_tile_per_wg = (algo & MNET_CONV_ALGO_FLAG_ONE_TILE) ? 1 : 0;
     algo &= ~MNET_CONV_ALGO_FLAG_ONE_TILE;
     MNET_CHECK_ARG((algo >= 0 && algo <= 3) || (algo >= MNET_CONV_ALGO_DMA_CFG0 && algo < MNET_CONV_ALGO_DMA_CFG0 + 16) ||
-                   (algo >= MNET_CONV_ALGO_STRIP_CFG0 && algo < MNET_CONV_ALGO_STRIP_CFG0 + 3), "conv: bad algo %d", algo);
+                   (algo >= MNET_CONV_ALGO_STRIP_CFG0 && algo < MNET_CONV_ALGO_STRIP_CFG0 + 3) ||
+                   (algo >= MNET_CONV_ALGO_DMA_CFG16 && algo < MNET_CONV_ALGO_DMA_CFG16 + 16), "conv: bad algo %d", algo);
     MNET_CHECK_ARG(d != nullptr, "conv: null descriptor");
     MNET_CHECK_ARG(d->dtype == MNET_F32 || d->dtype == MNET_F16 || d->dtype == MNET_F16X2, "conv: bad dtype %d", d->dtype);
     MNET_CHECK_ARG(d->x0 && d->wgt && d->y, "conv: null tensor pointer");
@@ -474,6 +475,10 @@ static int conv_resolve(const mnet_conv_desc* d, int32_t algo, const ConvArgs& a
     static const bool no_strip = [] { const char* e = getenv("MNET_DMA_NO_STRIP"); return e && atoi(e) != 0; }();   // A/B knob
     const bool dma_ok = conv_dma_eligible(a, d->dtype);
     const int strip = conv_strip_pick(a, d->dtype, algo >= MNET_CONV_ALGO_STRIP_CFG0);
+    if (algo >= MNET_CONV_ALGO_DMA_CFG16) {
+        if (!dma_ok) return mnet_fail(MNET_E_ARG, "conv: this launch is not eligible for the LDS-DMA kernel");
+        return algo;
+    }
     if (algo >= MNET_CONV_ALGO_STRIP_CFG0) {
         if (strip != algo - MNET_CONV_ALGO_STRIP_CFG0)
             return mnet_fail(MNET_E_ARG, "conv: strip configuration %d is not the one this launch is eligible for (%d)",
@@ -491,7 +496,10 @@ static int conv_resolve(const mnet_conv_desc* d, int32_t algo, const ConvArgs& a
         return mnet_fail(MNET_E_ARG, "conv: LDS-DMA algo needs f16 (cin %% 64 == 0) or split-half (cin %% 32 == 0), cout >= 64, cout %% 8 == 0 and no input transform");
     if (algo >= MNET_CONV_ALGO_DMA_CFG0) return algo;
     if (algo != MNET_CONV_ALGO_REG_STAGED && strip >= 0 && !no_strip) return MNET_CONV_ALGO_STRIP_CFG0 + strip;
-    if (dma_ok && algo != MNET_CONV_ALGO_REG_STAGED) return MNET_CONV_ALGO_DMA_CFG0 + conv_dma_pick(a);
+    if (dma_ok && algo != MNET_CONV_ALGO_REG_STAGED) {
+        const int id = conv_dma_pick(a);
+        return id < 16 ? MNET_CONV_ALGO_DMA_CFG0 + id : MNET_CONV_ALGO_DMA_CFG16 + (id - 16);
+    }
     return MNET_CONV_ALGO_REG_STAGED;
 }
 
@@ -509,6 +517,7 @@ extern "C" int mnet_conv2d_nhwc_ex(const mnet_conv_desc* d, int32_t algo, void* 
     const int k = conv_resolve(d, algo, a);
     if (k < 0) return k;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    if (k >= MNET_CONV_ALGO_DMA_CFG16) return launch_conv_dma(a, st, k - MNET_CONV_ALGO_DMA_CFG16 + 16);
     if (k >= MNET_CONV_ALGO_STRIP_CFG0) return launch_conv_strip(a, st, k - MNET_CONV_ALGO_STRIP_CFG0);
     if (k >= MNET_CONV_ALGO_DMA_CFG0) return launch_conv_dma(a, st, k - MNET_CONV_ALGO_DMA_CFG0);
     if (k == MNET_CONV_ALGO_SKINNY) return launch_conv_skinny(a, st);

@@ -237,6 +237,40 @@ __global__ void __launch_bounds__(WC * WP * 64, WC * WP / 4) conv_dma_kernel(con
         }
     };
 
+    // f16 slab with both half slabs' fragments requested up front (PIPE, 8-wave tiles: 256 VGPRs): the second half's LDS reads run
+    // under the first half's MFMAs; the next slab's DMA pieces go out between the halves
+    auto compute_f16_pipe = [&](int stage, auto&& between) __attribute__((always_inline)) {
+        const unsigned char* sw_ = smem + stage * STAGE;
+        const unsigned char* sx_ = sw_ + BC * 128;
+        u32x4 a0[FC], b0[FP], a1[FC], b1[FP];
+#pragma unroll
+        for (int f = 0; f < FC; ++f) a0[f] = *reinterpret_cast<const u32x4*>(sw_ + swz_dma(wc * (BC / WC) + f * 16 + l16, g));
+#pragma unroll
+        for (int f = 0; f < FP; ++f) b0[f] = *reinterpret_cast<const u32x4*>(sx_ + swz_dma(wp * (BP / WP) + f * 16 + l16, g));
+#pragma unroll
+        for (int f = 0; f < FC; ++f) a1[f] = *reinterpret_cast<const u32x4*>(sw_ + swz_dma(wc * (BC / WC) + f * 16 + l16, 4 + g));
+#pragma unroll
+        for (int f = 0; f < FP; ++f) b1[f] = *reinterpret_cast<const u32x4*>(sx_ + swz_dma(wp * (BP / WP) + f * 16 + l16, 4 + g));
+#pragma unroll
+        for (int fa = 0; fa < FC; ++fa)
+#pragma unroll
+            for (int fb = 0; fb < FP; ++fb)
+                acc[fa][fb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bitcast<f16x8>(a0[fa]), bitcast<f16x8>(b0[fb]), acc[fa][fb], 0, 0, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, FC + FP, 0);
+#pragma unroll
+        for (int i = 0; i < FC + FP; ++i) {
+            __builtin_amdgcn_sched_group_barrier(0x008, (FC * FP) / (FC + FP), 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        }
+        __builtin_amdgcn_sched_group_barrier(0x008, (FC * FP) - ((FC * FP) / (FC + FP)) * (FC + FP), 0);
+        between();
+#pragma unroll
+        for (int fa = 0; fa < FC; ++fa)
+#pragma unroll
+            for (int fb = 0; fb < FP; ++fb)
+                acc[fa][fb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bitcast<f16x8>(a1[fa]), bitcast<f16x8>(b1[fb]), acc[fa][fb], 0, 0, 0);
+    };
+
     // split-half slab: 32 channels, hi halves in chunks 0-3 and lo halves in chunks 4-7 of every row; x*w = hi*hi + hi*lo + lo*hi
     // (lo*lo is below fp32 resolution) — the same fp32 accumulators take all three products
     auto compute_x3 = [&](int stage, auto&& after_first, auto&& after_second) __attribute__((always_inline)) {
@@ -332,6 +366,8 @@ __global__ void __launch_bounds__(WC * WP * 64, WC * WP / 4) conv_dma_kernel(con
                     compute_x3(c_stage,
                                [&]() __attribute__((always_inline)) { __builtin_amdgcn_sched_barrier(0); issue_w(i_stage); issue_x(i_stage); adv(); __builtin_amdgcn_sched_barrier(0); },
                                [] {});
+                } else if constexpr (PIPE) {
+                    compute_f16_pipe(c_stage, [&]() __attribute__((always_inline)) { __builtin_amdgcn_sched_barrier(0); issue_w(i_stage); issue_x(i_stage); adv(); __builtin_amdgcn_sched_barrier(0); });
                 } else {
                     compute_half(c_stage, 0);
                     __builtin_amdgcn_sched_barrier(0);
@@ -441,6 +477,10 @@ static int launch_dma_id(int id, const ConvArgs& a, hipStream_t st) {
         case 7: return launch_dma_cfg<256, 256, 4, 4, 2, 32>(a, st);
         case 8: return launch_dma_cfg<256, 256, 4, 4, 2, 16, 0, false, true>(a, st);       // id 0 with the DMA pieces issued between the two half slabs
         case 9: return launch_dma_cfg<128, 512, 2, 8, 2, 16, 0, false, true>(a, st);       // id 4, same
+        case 16: return launch_dma_cfg<256, 256, 2, 4, 2, 16, 0, false, true, true>(a, st);   // 8 waves (128x64 per wave), both half slabs' fragments requested up
+                                                                                            // front (the second half's LDS reads run under the first half's MFMAs),
+                                                                                            // DMA pieces between the halves: AUTO for cout >= 256
+        case 17: return launch_dma_cfg<128, 512, 2, 4, 2, 16, 0, false, true, true>(a, st);   // the same form of the 128x512 tile (64x128 per wave)
         case 10: return launch_dma_cfg<128, 128, 2, 4, 4>(a, st);          // small launches: twice the workgroups of ids 1 / 2, 3 slabs in flight
         case 11: return launch_dma_cfg<256, 256, 4, 4, 2, 16, 4>(a, st);  // DIAGNOSTIC: all tiles store over tile 0; stamps after tile 0
         case 12: return launch_dma_cfg<256, 256, 4, 4, 2, 16, 5>(a, st);  // DIAGNOSTIC: no output stores; stamps after tile 0
@@ -453,7 +493,7 @@ static int launch_dma_id(int id, const ConvArgs& a, hipStream_t st) {
 
 int conv_dma_pick(const ConvArgs& a) {
     const bool big = a.npix >= 256 * 256;
-    static const int env_big256 = [] { const char* e = getenv("MNET_DMA_CFG_BIG256"); return e ? atoi(e) : 8; }();   // A/B knob
+    static const int env_big256 = [] { const char* e = getenv("MNET_DMA_CFG_BIG256"); return e ? atoi(e) : 16; }();   // A/B knob
     // a launch that would leave a quarter or more of the CUs without a tile (a strip at a time: 4096-16384 pixels) takes the
     // 128x128 tile instead: twice the workgroups (same k order, same bits)
     const long long t128 = (a.npix + 127) / 128, t256 = (a.npix + 255) / 256;
@@ -472,7 +512,10 @@ int conv_dma_pick(const ConvArgs& a) {
     static const int env_x3_256 = [] { const char* e = getenv("MNET_X3_CFG256"); return e ? atoi(e) : 11; }();
     if (a.split && big && a.cout >= 128) return env_x3_16w ? (a.cout >= 256 ? 0 : 4) : (a.cout >= 256 ? env_x3_256 : env_x3_128);
     // f16 big tiles: ids 8 / 9 = ids 0 / 4 with the next slab's DMA pieces issued between the two half slabs instead of right after
-    // the barrier (+2.8 % on the 256x256 tile: 1140 vs 1109 TFLOP/s, B = 64; same MFMA sequence, same bits)
+    // the barrier (+2.8 % on the 256x256 tile: 1140 vs 1109 TFLOP/s, B = 64; same MFMA sequence, same bits).  id 16 = the 8-wave
+    // 256x256 tile with both half slabs' fragments requested up front as well (the second half's LDS reads run under the first
+    // half's MFMAs — it has the registers for it): 1176-1188 vs 1148-1166 TFLOP/s for id 8, 1064 for the plain 8-wave id 6 → AUTO
+    // for cout >= 256; the same form of the 128x512 tile (id 17) is slower than id 9 (22.3 vs 18.3 ms per step)
     static const int env_big128 = [] { const char* e = getenv("MNET_DMA_CFG_BIG128"); return e ? atoi(e) : 9; }();   // A/B knob
     if (a.cout >= 256) return big ? env_big256 : (t128 * ((a.cout + 255) / 256) < 200 ? 10 : 1);
     if (a.cout >= 128) return big ? env_big128 : (t256 * ((a.cout + 127) / 128) < 200 ? 10 : 2);

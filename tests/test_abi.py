@@ -73,7 +73,8 @@ def test_argument_validation_without_device():
     d2.dtype = 1; d2.x0 = 16; d2.wgt = 16; d2.y = 16; d2.n = 64; d2.h = d2.ho = 32; d2.w = d2.wo = 32
     d2.c0 = 64; d2.kh = d2.kw = 3; d2.stride_h = d2.stride_w = 1; d2.pad_h = d2.pad_w = 1
     d2.cout = 256
-    assert lib.mnet_conv2d_plan(ctypes.byref(d2), _lib.ALGO_AUTO) == _lib.ALGO_DMA_CFG0 + 8        # 256x256 LDS-DMA tile (DMA between the half slabs)
+    assert lib.mnet_conv2d_plan(ctypes.byref(d2), _lib.ALGO_AUTO) == _lib.ALGO_DMA_CFG16           # 256x256 LDS-DMA tile, 8-wave pipelined form (id 16)
+    assert lib.mnet_conv2d_plan(ctypes.byref(d2), _lib.ALGO_DMA_CFG0 + 8) == _lib.ALGO_DMA_CFG0 + 8
     assert lib.mnet_conv2d_plan(ctypes.byref(d2), _lib.ALGO_STRIP_CFG0) == _lib.ALGO_STRIP_CFG0    # strip form by explicit request
     d2.cout = 64
     assert lib.mnet_conv2d_plan(ctypes.byref(d2), _lib.ALGO_AUTO) == _lib.ALGO_STRIP_CFG0 + 1      # strip kernel, 64x512 tile

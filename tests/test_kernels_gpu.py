@@ -407,15 +407,16 @@ def test_conv_lds_dma_kernel(case):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("cfg", [0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10])
+@pytest.mark.parametrize("cfg", [0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 16, 17])
 @pytest.mark.parametrize("shape", [(3, 40, 52, 64, 64, 200, 3), (700, 4, 4, 128, 0, 72, 3), (2, 9, 300, 192, 0, 320, 1)])
 def test_conv_lds_dma_every_tile_config(cfg, shape):
     """every LDS-DMA tile configuration, pinned explicitly, is bit-identical to the register-staged kernel on shapes with
     cout / pixel tails, two concat sources and ragged valid widths (ids in include/marconet_hip.h)"""
     ops = _ops()
-    from marconet_amd._lib import ALGO_DMA_CFG0
+    from marconet_amd._lib import ALGO_DMA_CFG0, ALGO_DMA_CFG16
     dtype = torch.float16
     n, h, w, c0, c1, cout, k = shape
+    algo_cfg = ALGO_DMA_CFG0 + cfg if cfg < 16 else ALGO_DMA_CFG16 + (cfg - 16)
     x = _q(_rnd((n, c0 + c1, h, w), 71), dtype)
     wt = _q(_rnd((cout, c0 + c1, k, k), 72, 1.0 / math.sqrt((c0 + c1) * k * k)), dtype)
     bias = _rnd((cout,), 73, 0.3)
@@ -425,7 +426,7 @@ def test_conv_lds_dma_every_tile_config(cfg, shape):
     x0 = _nhwc(x[:, :c0], dtype)
     x1 = _nhwc(x[:, c0:], dtype) if c1 else None
     kw = dict(x1=x1, valid_w=vw, out_scale=osc.to(DEV), bias=bias.to(DEV), residual=res, act=ops.ACT_LRELU_SQRT2)
-    y_cfg = ops.conv2d(x0, _pack_w(wt, dtype), cout, k, k, (1, 1), (k // 2, k // 2), algo=ALGO_DMA_CFG0 + cfg, **kw)
+    y_cfg = ops.conv2d(x0, _pack_w(wt, dtype), cout, k, k, (1, 1), (k // 2, k // 2), algo=algo_cfg, **kw)
     y_reg = ops.conv2d(x0, _pack_w(wt, dtype), cout, k, k, (1, 1), (k // 2, k // 2), algo=1, **kw)
     torch.cuda.synchronize()
     # same products as the register-staged kernel, fp32 partial sums associated differently (k order / MFMA shape)
