@@ -329,6 +329,11 @@ def main():
         "roofline": roofline,
         "secondary": secondary,
     }
+    if a.config == "sr":
+        out["headline_note"] = ("value is measured in the %s precision mode. fp16x3 (split-half storage, hi*hi + hi*lo + lo*hi on the fp16 MFMA) is the "
+                                "throughput mode that meets the north-star parity bar (<= 1e-3, indices bit-exact; see parity); the plain fp16 "
+                                "storage mode — BASELINE configs[1]'s type and round 1's headline, ~1e-2 deviation — is secondary.fp16_mode_images_per_s, "
+                                "the exact fp32 mode secondary.fp32_mode_images_per_s" % a.precision)
     roofline["end_to_end_frac_of_peak"] = round(out["value"] / world * gf_image / 1e3 / peak, 4)
     if world > 1:
         out["ranks"] = {"world_size": dist.get_world_size(), "backend": dist.get_backend(),
