@@ -36,5 +36,5 @@ def test_sharded_forward_equals_single_gpu(total, tmp_path):
         assert p.wait(timeout=900) == 0
     res = json.load(open(out))
     assert res["world"] == world and res["backend"] == "nccl"
-    for k in ("fp32.u8_bgr", "fp32.nchw_f32", "fp16.u8_bgr", "fp16.nchw_f32"):
+    for k in ("fp32.u8_bgr", "fp32.nchw_f32", "fp16x3.u8_bgr", "fp16x3.nchw_f32", "fp16.u8_bgr", "fp16.nchw_f32"):
         assert res[k], "%s: gathered result differs from the single-GPU result" % k
