@@ -437,7 +437,8 @@ def test_forward_blind_runs_end_to_end(nets):
     assert sr.shape == (2, 3, 128, 2048) and torch.isfinite(sr).all() and len(labels) == 2 and locs.shape == (2, 32)
 
 
-def test_full_size_batch_properties_fp16(nets):
+@pytest.mark.parametrize("precision", ["fp16", "fp16x3"])
+def test_full_size_batch_properties_fp16(nets, precision):
     """BASELINE configs[1] at full size (64 strips x 16 glyphs, fp16 throughput mode), checked through size-independent
     properties instead of the (hours-long) CPU oracle: the batch equals its two halves run separately bit for bit (what
     makes an N-GPU data-parallel run equal the 1-GPU run), images are processed independently (a permuted
@@ -447,7 +448,7 @@ def test_full_size_batch_properties_fp16(nets):
     lq = synth.make_lq(91, B, [512] * B).to(DEV)
     labels = [synth.make_labels(100 + b, n).to(DEV) for b in range(B)]
     locs = synth.make_locs([n] * B, [512] * B).to(DEV)
-    pipe = MarconetPipeline(*nets, precision="fp16")
+    pipe = MarconetPipeline(*nets, precision=precision)
     try:
         full = pipe.forward_batch(lq, labels, locs)
         assert full.shape == (B, 3, 128, 2048) and torch.isfinite(full).all() and float(full.abs().max()) <= 1.0
