@@ -429,12 +429,33 @@ def test_clear_labels_locs_and_w_interpolation(nets, ckpts):
         assert _err(imgs[i], ref) <= TOL
 
 
-def test_forward_blind_runs_end_to_end(nets):
+def test_forward_blind_vs_oracle(nets, ckpts):
+    """the self-contained pass (labels = clear_labels(logits), test_w.py:34-40; locs = (left, right) → (centre, half-width),
+    Train/tspgan/models/tspgan_model.py:331-336) against the same chain built from the oracle: identical labels, locs and SR <= 1e-3"""
     from marconet_amd.pipeline import MarconetPipeline
     pipe = MarconetPipeline(*nets, precision="fp32")
-    lq = synth.make_lq(81, 2, [400, 512]).to(DEV)
-    sr, labels, locs = pipe.forward_blind(lq)
+    lq = synth.make_lq(81, 2, [400, 512])
+    sr, labels, locs = pipe.forward_blind(lq.to(DEV))
     assert sr.shape == (2, 3, 128, 2048) and torch.isfinite(sr).all() and len(labels) == 2 and locs.shape == (2, 32)
+    with torch.no_grad():
+        logits, enc_locs, w = O.encoder_forward(ckpts[0], lq)
+        l, r = enc_locs[:, 0::2], enc_locs[:, 1::2]
+        locs_ref = torch.stack(((r + l) / 2.0, (r - l) / 2.0), dim=2).reshape(2, 32)
+        assert _err(locs, locs_ref) <= 1e-5
+        p64, p32 = [], []
+        for b in range(2):
+            lab = [int(v) for v in O.clear_labels(logits[b])][:16]
+            assert labels[b].flatten().tolist() == lab
+            if lab:
+                _, a, c = O.tspgan_forward(ckpts[1], w[b:b + 1].repeat(len(lab), 1), torch.tensor(lab).reshape(-1, 1))
+            else:
+                a, c = torch.zeros(0, 256, 64, 64), torch.zeros(0, 512, 32, 32)
+            p64.append(a)
+            p32.append(c)
+        ref = O.tspsr_forward(ckpts[2], lq, p64, p32, locs_ref)
+    e = _err(sr, ref)
+    _note("sr.fp32.forward_blind.maxabs", e)
+    assert e <= TOL
 
 
 @pytest.mark.parametrize("precision", ["fp16", "fp16x3"])
