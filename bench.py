@@ -275,11 +275,13 @@ def main():
     ops.stats.enabled = ops.stats.timing = False
     if y.dtype.is_floating_point:
         assert torch.isfinite(y).all()
-    total_images = images_per_step
+    total_images, per_rank_images = images_per_step, [images_per_step]
     if world > 1:
         t = torch.tensor([images_per_step], device=dev, dtype=torch.float64)
-        dist.all_reduce(t)
-        total_images = int(t.item())
+        allc = [torch.zeros_like(t) for _ in range(world)]
+        dist.all_gather(allc, t)
+        per_rank_images = [int(v.item()) for v in allc]
+        total_images = sum(per_rank_images)
     roofline, peak = conv_roofline(ops, a.steps, alg_gf_step, pdt, B if a.config == "sr" else None, a.precision)
 
     # ---- secondary figures (reported separately, never the headline)
@@ -337,7 +339,7 @@ def main():
     roofline["end_to_end_frac_of_peak"] = round(out["value"] / world * gf_image / 1e3 / peak, 4)
     if world > 1:
         out["ranks"] = {"world_size": dist.get_world_size(), "backend": dist.get_backend(),
-                        "per_rank_images_per_s": [round(images_per_step * a.steps / t_, 2) for t_ in per_rank_dt]}
+                        "per_rank_images_per_s": [round(c_ * a.steps / t_, 2) for c_, t_ in zip(per_rank_images, per_rank_dt)]}
 
     # ---- CPU baseline (the oracle = port of the reference's CPU forward) + parity, rank 0 at N=1 only
     if rank == 0 and world == 1 and a.cpu_images > 0 and a.config == "sr":
