@@ -10,6 +10,9 @@ typedef f16 f16x4 __attribute__((ext_vector_type(4)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));   // one raw 16-byte chunk
 typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+typedef f16 f16x2 __attribute__((ext_vector_type(2)));
+typedef short s16x2 __attribute__((ext_vector_type(2)));
+typedef int i32x8 __attribute__((ext_vector_type(8)));
 
 // host-side error plumbing (defined in api.hip)
 int mnet_fail(int code, const char* fmt, ...);

@@ -32,7 +32,14 @@
 // SPREAD (hot iterations of 2-stage tiles): instead of issuing all of a slab's DMA pieces right after the slab barrier — when every
 //     wave of the workgroup does the same and the matrix pipe idles — the weight pieces go out after the first third / half of
 //     the slab's multiplies and the activation pieces after the second.
-template <int BC, int BP, int WC, int WP, int STAGES, int MF = 16, int DBG = 0, bool X3 = false, bool SPREAD = false, bool PIPE = false>
+// MX (with X3, MF = 32): "fp16+8" launch (MNET_F16M) — same 128-byte block per 32 channels, but only the hi part is a half:
+//     activations  chunks 0-3 hi (f16) | chunk 4 lo8 of channels {0-7,16-23} | chunk 5 lo8 of {8-15,24-31} | chunk 6 byte 0: E8M0 scale
+//     weights      chunks 0-3 hi (f16) | chunk 4 lo8 {0-7,16-23} | chunk 5 hi8 {0-7,16-23} | chunk 6 lo8 {8-15,24-31} | chunk 7 hi8 {8-15,24-31}
+//     (lo8 = e4m3(lo * 2^11 / s), hi8 = e4m3(hi / s), s = 2^(E - 127): per (pixel, block) for activations, per output channel for weights).
+//     x*w = hi*hi on v_mfma_f32_32x32x16_f16 + (w_lo8*x_hi8 + w_hi8*x_lo8) as ONE v_mfma_scale_f32_32x32x64_f8f6f4 (2x rate, the
+//     block scales s_w * s_x * 2^-11 applied by the instruction): 2 MFMA units per product instead of 3.  x_hi8 is converted from
+//     the f16 fragments the lane already holds (v_cvt_scalef32_pk_fp8_f16).
+template <int BC, int BP, int WC, int WP, int STAGES, int MF = 16, int DBG = 0, bool X3 = false, bool SPREAD = false, bool PIPE = false, bool MX = false>
 __global__ void __launch_bounds__(WC * WP * 64, WC * WP / 4) conv_dma_kernel(const ConvArgs p) {
     constexpr int NW = WC * WP;                          // waves per workgroup (8 or 16)
     constexpr int FC = BC / WC / 16, FP = BP / WP / 16;
@@ -41,8 +48,8 @@ __global__ void __launch_bounds__(WC * WP * 64, WC * WP / 4) conv_dma_kernel(con
     constexpr int STAGE = (BC + BP) * 128;
     constexpr unsigned OOB = 0x80000000u;                // beyond every num_records used below
     static_assert(NW == 8 || NW == 16, "8 or 16 waves");
-    static_assert(!X3 || MF == 16, "the split-half form uses v_mfma_f32_16x16x32_f16");
-    static_assert(!SPREAD || (STAGES == 2 && MF == 16 && DBG == 0), "SPREAD: production 2-stage tiles only");
+    static_assert(!MX || (X3 && MF == 32 && STAGES == 2), "MX: 4-byte storage, 32x32 MFMAs, 2-stage tiles (plain vmcnt(0) waits)");
+    static_assert(!SPREAD || (STAGES == 2 && (MF == 16 || X3) && DBG == 0), "SPREAD: production 2-stage tiles only");
     static_assert(WJ >= 1 && XJ >= 1 && WJ * 8 * NW == BC && XJ * 8 * NW == BP, "tile / wave-count mismatch");
     static_assert(STAGES == 2 || ((STAGES == 3 || STAGES == 4) && NDMA >= 4 && NDMA <= 6), "vmcnt immediates below cover 4-6 DMAs per slab, up to 3 slabs in flight");
     static_assert((BC / WC) % 64 == 0 && (BP / WP) % 32 == 0, "the channel permutation works on 64-channel blocks of a wave tile");
@@ -318,6 +325,128 @@ __global__ void __launch_bounds__(WC * WP * 64, WC * WP / 4) conv_dma_kernel(con
                 acc[fa][fb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bitcast<f16x8>(a[fa]), bitcast<f16x8>(bh[fb]), acc[fa][fb], 0, 0, 0);
     };
 
+    // split-half slab on v_mfma_f32_32x32x16_f16: lane = (row lane & 31, k half h = lane >> 5); the 16-deep k-step k2 of the hi part
+    // is chunk 2 k2 + h, of the lo part chunk 4 + 2 k2 + h.  Half the matrix instructions (and operand register reads) per FLOP of
+    // the 16x16x32 form
+    auto compute_x3_32 = [&](int stage, auto&& between) __attribute__((always_inline)) {
+        const unsigned char* sw_ = smem + stage * STAGE;
+        const unsigned char* sx_ = sw_ + BC * 128;
+        const int l32 = lane & 31, h = lane >> 5;
+        constexpr int FA = FC / 2, FB = FP / 2;
+        u32x4 a[2][FA], bh[2][FB], bl[2][FB];
+#pragma unroll
+        for (int k2 = 0; k2 < 2; ++k2) {
+#pragma unroll
+            for (int f = 0; f < FA; ++f) a[k2][f] = *reinterpret_cast<const u32x4*>(sw_ + swz_dma(wc * (BC / WC) + f * 32 + l32, 2 * k2 + h));
+#pragma unroll
+            for (int f = 0; f < FB; ++f) bh[k2][f] = *reinterpret_cast<const u32x4*>(sx_ + swz_dma(wp * (BP / WP) + f * 32 + l32, 2 * k2 + h));
+        }
+#pragma unroll
+        for (int k2 = 0; k2 < 2; ++k2)
+#pragma unroll
+            for (int fa = 0; fa < FA; ++fa)
+#pragma unroll
+                for (int fb = 0; fb < FB; ++fb)
+                    acc32[fa][fb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bitcast<f16x8>(a[k2][fa]), bitcast<f16x8>(bh[k2][fb]), acc32[fa][fb], 0, 0, 0);
+        between();
+#pragma unroll
+        for (int k2 = 0; k2 < 2; ++k2)
+#pragma unroll
+            for (int f = 0; f < FB; ++f) bl[k2][f] = *reinterpret_cast<const u32x4*>(sx_ + swz_dma(wp * (BP / WP) + f * 32 + l32, 4 + 2 * k2 + h));
+#pragma unroll
+        for (int k2 = 0; k2 < 2; ++k2)
+#pragma unroll
+            for (int fa = 0; fa < FA; ++fa)
+#pragma unroll
+                for (int fb = 0; fb < FB; ++fb)
+                    acc32[fa][fb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bitcast<f16x8>(a[k2][fa]), bitcast<f16x8>(bl[k2][fb]), acc32[fa][fb], 0, 0, 0);
+#pragma unroll
+        for (int k2 = 0; k2 < 2; ++k2)
+#pragma unroll
+            for (int f = 0; f < FA; ++f) a[k2][f] = *reinterpret_cast<const u32x4*>(sw_ + swz_dma(wc * (BC / WC) + f * 32 + l32, 4 + 2 * k2 + h));
+#pragma unroll
+        for (int k2 = 0; k2 < 2; ++k2)
+#pragma unroll
+            for (int fa = 0; fa < FA; ++fa)
+#pragma unroll
+                for (int fb = 0; fb < FB; ++fb)
+                    acc32[fa][fb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bitcast<f16x8>(a[k2][fa]), bitcast<f16x8>(bh[k2][fb]), acc32[fa][fb], 0, 0, 0);
+    };
+
+    // fp16+8 slab (see the MX note above the kernel)
+    int mx_sa[MF == 32 ? FC / 2 : 1];                      // per weight fragment: E8M0 byte of s_w * 2^-11 for this lane's row (constant over k)
+    auto compute_mx = [&](int stage, auto&& between) __attribute__((always_inline)) {
+        const unsigned char* sw_ = smem + stage * STAGE;
+        const unsigned char* sx_ = sw_ + BC * 128;
+        const int l32 = lane & 31, h = lane >> 5;
+        constexpr int FA = FC / 2, FB = FP / 2;
+        u32x4 a[2][FA], bh[2][FB];
+#pragma unroll
+        for (int k2 = 0; k2 < 2; ++k2) {
+#pragma unroll
+            for (int f = 0; f < FA; ++f) a[k2][f] = *reinterpret_cast<const u32x4*>(sw_ + swz_dma(wc * (BC / WC) + f * 32 + l32, 2 * k2 + h));
+#pragma unroll
+            for (int f = 0; f < FB; ++f) bh[k2][f] = *reinterpret_cast<const u32x4*>(sx_ + swz_dma(wp * (BP / WP) + f * 32 + l32, 2 * k2 + h));
+        }
+        i32x8 b8[FB];
+        int eb[FB];
+#pragma unroll
+        for (int f = 0; f < FB; ++f) {
+            const unsigned char* row = sx_ + (wp * (BP / WP) + f * 32 + l32) * 128;
+            const int sw3 = ((wp * (BP / WP) + f * 32 + l32) >> 1) & 7;
+            eb[f] = *(row + ((6 ^ sw3) << 4));                              // E8M0 of the block scale s_x
+            const u32x4 lo8 = *reinterpret_cast<const u32x4*>(row + (((4 + h) ^ sw3) << 4));
+            b8[f][4] = (int)lo8[0]; b8[f][5] = (int)lo8[1]; b8[f][6] = (int)lo8[2]; b8[f][7] = (int)lo8[3];
+        }
+#pragma unroll
+        for (int k2 = 0; k2 < 2; ++k2)
+#pragma unroll
+            for (int fa = 0; fa < FA; ++fa)
+#pragma unroll
+                for (int fb = 0; fb < FB; ++fb)
+                    acc32[fa][fb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bitcast<f16x8>(a[k2][fa]), bitcast<f16x8>(bh[k2][fb]), acc32[fa][fb], 0, 0, 0);
+        between();
+        // x_hi8 of this lane's 16 channels (the two f16 chunks it holds): e4m3(hi / s_x)
+#pragma unroll
+        for (int f = 0; f < FB; ++f) {
+            const int e = eb[f];
+#pragma unroll
+            for (int k2 = 0; k2 < 2; ++k2)
+#pragma unroll
+                for (int d = 0; d < 2; ++d) {
+                    s16x2 r = {0, 0};
+                    if (p.mx_cvt == 2) {            // exact power-of-two multiply, then an unscaled conversion
+                        const f16 m = (f16)__builtin_bit_cast(float, (unsigned)(254 - e) << 23);
+                        const f16x2 mm = {m, m};
+                        r = __builtin_amdgcn_cvt_scalef32_pk_fp8_f16(r, bitcast<f16x2>(bh[k2][f][2 * d]) * mm, 1.0f, false);
+                        r = __builtin_amdgcn_cvt_scalef32_pk_fp8_f16(r, bitcast<f16x2>(bh[k2][f][2 * d + 1]) * mm, 1.0f, true);
+                    } else {
+                        const float sc = __builtin_bit_cast(float, (unsigned)(p.mx_cvt ? 254 - e : e) << 23);
+                        r = __builtin_amdgcn_cvt_scalef32_pk_fp8_f16(r, bitcast<f16x2>(bh[k2][f][2 * d]), sc, false);
+                        r = __builtin_amdgcn_cvt_scalef32_pk_fp8_f16(r, bitcast<f16x2>(bh[k2][f][2 * d + 1]), sc, true);
+                    }
+                    b8[f][2 * k2 + d] = bitcast<int>(r);
+                }
+        }
+        i32x8 a8[FA];
+#pragma unroll
+        for (int f = 0; f < FA; ++f) {
+            const u32x4 lo8 = *reinterpret_cast<const u32x4*>(sw_ + swz_dma(wc * (BC / WC) + f * 32 + l32, 4 + 2 * h));
+            const u32x4 hi8 = *reinterpret_cast<const u32x4*>(sw_ + swz_dma(wc * (BC / WC) + f * 32 + l32, 5 + 2 * h));
+            a8[f] = i32x8{(int)lo8[0], (int)lo8[1], (int)lo8[2], (int)lo8[3], (int)hi8[0], (int)hi8[1], (int)hi8[2], (int)hi8[3]};
+        }
+#pragma unroll
+        for (int fa = 0; fa < FA; ++fa)
+#pragma unroll
+            for (int fb = 0; fb < FB; ++fb)
+                acc32[fa][fb] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a8[fa], b8[fb], acc32[fa][fb], 0, 0, 0, mx_sa[fa], 0, eb[fb]);
+    };
+    auto compute_split = [&](int stage, auto&& between) __attribute__((always_inline)) {
+        if constexpr (MX) compute_mx(stage, between);
+        else if constexpr (MF == 32) compute_x3_32(stage, between);
+        else compute_x3(stage, between, [] {});
+    };
+
     // wait until at most `keep` (1 or 2) of this wave's slabs are still in flight: vmcnt(keep * NDMA), an immediate
     auto wait_keep = [&](int keep) {
         if (keep >= 2) { if constexpr (NDMA == 6) VMCNT(12); else if constexpr (NDMA == 5) VMCNT(10); else VMCNT(8); }
@@ -350,6 +479,18 @@ __global__ void __launch_bounds__(WC * WP * 64, WC * WP / 4) conv_dma_kernel(con
                     for (int q = 0; q < 16; ++q) acc32[a][b][q] = 0.f;
         }
 
+        if constexpr (MX) {             // E8M0 bytes of the weight scales (after the cout * K packed rows), one per output channel
+            int co0, pix0;
+            tile_coords(c_v, co0, pix0);
+            const unsigned char* wexp = reinterpret_cast<const unsigned char*>(p.wgt) + (size_t)p.cout * p.K * 2;
+#pragma unroll
+            for (int f = 0; f < FC / 2; ++f) {
+                const int ch = co0 + dma_weight_channel<32>(wc * (BC / WC) + f * 32 + (lane & 31));
+                mx_sa[f] = ch < p.cout ? (int)wexp[ch] : 0;
+            }
+            drain = true;               // plain loads share the vmcnt counter with the DMA: the next wait is vmcnt(0)
+        }
+
         // hot iterations: the slab issued stays inside this tile (same loop body as a non-persistent kernel)
         const int hot = nk - (STAGES - 1) > 0 ? nk - (STAGES - 1) : 0;
         for (int kt = 0; kt < hot; ++kt) {
@@ -363,9 +504,8 @@ __global__ void __launch_bounds__(WC * WP * 64, WC * WP / 4) conv_dma_kernel(con
                 // the DMA pieces of the next slab ride between the multiplies of this one (sched barriers pin the placement)
                 auto adv = [&]() __attribute__((always_inline)) { i_stage = i_stage == STAGES - 1 ? 0 : i_stage + 1; ++i_kt; };
                 if constexpr (X3) {
-                    compute_x3(c_stage,
-                               [&]() __attribute__((always_inline)) { __builtin_amdgcn_sched_barrier(0); issue_w(i_stage); issue_x(i_stage); adv(); __builtin_amdgcn_sched_barrier(0); },
-                               [] {});
+                    compute_split(c_stage,
+                                  [&]() __attribute__((always_inline)) { __builtin_amdgcn_sched_barrier(0); issue_w(i_stage); issue_x(i_stage); adv(); __builtin_amdgcn_sched_barrier(0); });
                 } else if constexpr (PIPE) {
                     compute_f16_pipe(c_stage, [&]() __attribute__((always_inline)) { __builtin_amdgcn_sched_barrier(0); issue_w(i_stage); issue_x(i_stage); adv(); __builtin_amdgcn_sched_barrier(0); });
                 } else {
@@ -377,7 +517,7 @@ __global__ void __launch_bounds__(WC * WP * 64, WC * WP / 4) conv_dma_kernel(con
                 }
             } else {
                 issue_hot();
-                if constexpr (X3) compute_x3(c_stage, [] {}, [] {});
+                if constexpr (X3) compute_split(c_stage, [] {});
                 else { compute_half(c_stage, 0); compute_half(c_stage, 1); }
             }
             c_stage = c_stage == STAGES - 1 ? 0 : c_stage + 1;
@@ -391,7 +531,7 @@ __global__ void __launch_bounds__(WC * WP * 64, WC * WP / 4) conv_dma_kernel(con
             __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");
             inflight += issue_next() - 1;
-            if constexpr (X3) compute_x3(c_stage, [] {}, [] {});
+            if constexpr (X3) compute_split(c_stage, [] {});
             else { compute_half(c_stage, 0); compute_half(c_stage, 1); }
             c_stage = c_stage == STAGES - 1 ? 0 : c_stage + 1;
         }
@@ -417,10 +557,10 @@ __global__ void __launch_bounds__(WC * WP * 64, WC * WP / 4) conv_dma_kernel(con
     }
 }
 
-template <int BC, int BP, int WC, int WP, int STAGES, int MF = 16, int DBG = 0, bool X3 = false, bool SPREAD = false, bool PIPE = false>
+template <int BC, int BP, int WC, int WP, int STAGES, int MF = 16, int DBG = 0, bool X3 = false, bool SPREAD = false, bool PIPE = false, bool MX = false>
 static int launch_dma_cfg(const ConvArgs& a, hipStream_t st) {
     constexpr int LDS = STAGES * (BC + BP) * 128;
-    auto kern = conv_dma_kernel<BC, BP, WC, WP, STAGES, MF, DBG, X3, SPREAD, PIPE>;
+    auto kern = conv_dma_kernel<BC, BP, WC, WP, STAGES, MF, DBG, X3, SPREAD, PIPE, MX>;
     static thread_local DeviceOnce attr_once;      // per instantiation, per thread, per device
     if (!attr_once.done()) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
@@ -463,6 +603,11 @@ static int launch_dma_id(int id, const ConvArgs& a, hipStream_t st) {
             case 11: return launch_dma_cfg<256, 256, 2, 4, 2, 16, 0, true, true, true>(a, st);   // id 8 + LDS reads placed by scheduling hints
             case 12: return launch_dma_cfg<128, 512, 2, 4, 2, 16, 0, true, true, true>(a, st);   // id 9, same
             case 10: return launch_dma_cfg<128, 128, 2, 4, 4, 16, 0, true>(a, st);
+            case 20: return launch_dma_cfg<256, 256, 2, 4, 2, 32, 0, true, true>(a, st);          // id 8 on v_mfma_f32_32x32x16_f16
+            case 21: return launch_dma_cfg<128, 512, 2, 4, 2, 32, 0, true, true>(a, st);          // id 9, same
+            case 24: return launch_dma_cfg<256, 256, 2, 4, 2, 32, 0, true, true, false, true>(a, st);   // fp16+8 (MX) operands, 256x256
+            case 25: return launch_dma_cfg<128, 512, 2, 4, 2, 32, 0, true, true, false, true>(a, st);   // fp16+8, 128x512
+            case 26: return launch_dma_cfg<64, 512, 1, 8, 2, 32, 0, true, true, false, true>(a, st);    // fp16+8, 64x512
             default: return mnet_fail(MNET_E_ARG, "conv: LDS-DMA tile configuration %d has no split-half form", id);
         }
     }

@@ -114,7 +114,7 @@ def conv2d(x0, wgt, cout, kh=1, kw=1, stride=(1, 1), pad=(0, 0), x1=None, in_sca
     _need_cuda(x0, x1, wgt, in_scale, in_shift, valid_w, out_scale, bias, residual, post_scale, out)
     n, h, w, c0 = x0.shape
     c1 = 0 if x1 is None else x1.shape[3]
-    if wgt.dtype != x0.dtype or wgt.numel() != cout * kh * kw * (c0 + c1):
+    if wgt.dtype != x0.dtype or (wgt.numel() != cout * kh * kw * (c0 + c1) and not (x0.dtype == SPLIT_DTYPE and wgt.numel() > cout * kh * kw * (c0 + c1))):
         raise RuntimeError("conv2d: weight dtype/shape mismatch (%s %s vs cout=%d k=%dx%d cin=%d)"
                            % (wgt.dtype, tuple(wgt.shape), cout, kh, kw, c0 + c1))
     ho = (h + 2 * pad[0] - kh) // stride[0] + 1

@@ -170,13 +170,15 @@ class MarconetPipeline:
 
 
     @torch.no_grad()
-    def forward_sharded(self, lq, labels, locs, output="u8_bgr", group=None):
+    def forward_sharded(self, lq, labels, locs, output="u8_bgr", group=None, force_collective=False):
         """Data-parallel form of forward_batch: every rank of the process group (one process per GPU; backend
         'nccl' = RCCL over xGMI) is handed the SAME global batch description (lq [B,3,32,512] on the host or on the rank's
         device, labels list, locs [B,2m]), processes its contiguous shard ``shard_range(B, rank, world)`` and all-gathers the
         outputs — the one collective of the path; by default the post-processed uint8 BGR image (0.75 MiB per image instead of
         the 3 MiB fp32 tensor).  → [B,128,2048,3] uint8 (or [B,3,128,2048] fp32 for output="nchw_f32") on every rank, equal
-        bit for bit to a single-GPU forward_batch of the whole batch (kernels are batch-invariant)."""
+        bit for bit to a single-GPU forward_batch of the whole batch (kernels are batch-invariant).
+        ``force_collective``: run the all-gather even in a world of one (an initialised process group is required) — the
+        RCCL path exercised on a single-GPU box."""
         import torch.distributed as dist
         world = dist.get_world_size(group) if dist.is_initialized() else 1
         rank = dist.get_rank(group) if dist.is_initialized() else 0
@@ -188,7 +190,11 @@ class MarconetPipeline:
         else:                         # more ranks than images: an empty shard still takes part in the collective
             shape = (0, 128, 4 * lq.shape[3], 3) if output == "u8_bgr" else (0, 3, 128, 4 * lq.shape[3])
             y = torch.empty(shape, dtype=torch.uint8 if output == "u8_bgr" else torch.float32, device=dev)
-        return y if world == 1 else all_gather_outputs(y, B, group)
+        if world == 1 and not force_collective:
+            return y
+        if not dist.is_initialized():
+            raise RuntimeError("forward_sharded(force_collective=True) needs an initialised process group")
+        return all_gather_outputs(y, B, group, force=force_collective)
 
     @torch.no_grad()
     def restore_strips(self, strips):
@@ -337,12 +343,13 @@ def shard_range(total, rank, world):
     return start, start + base + (1 if rank < rem else 0)
 
 
-def all_gather_outputs(local, total, group=None):
+def all_gather_outputs(local, total, group=None, force=False):
     """all-gather of per-rank SR outputs [b_r,...] → [total,...] on every rank (RCCL over xGMI when the
-    backend is 'nccl'; gloo in the CPU tests).  Uneven shards are padded to the largest shard."""
+    backend is 'nccl'; gloo in the CPU tests).  Uneven shards are padded to the largest shard.  A world of one returns
+    ``local`` without a collective unless ``force`` (the collective then really runs: one rank gathering from itself)."""
     import torch.distributed as dist
     world = dist.get_world_size(group)
-    if world == 1:
+    if world == 1 and not force:
         return local
     sizes = [shard_range(total, r, world) for r in range(world)]
     mx = max(b - a for a, b in sizes)

@@ -163,3 +163,30 @@ def test_host_side_label_and_loc_helpers():
     lr = torch.rand(3, 32)
     out = locs_from_left_right(lr)
     assert torch.allclose(out[:, 0::2], (lr[:, 1::2] + lr[:, 0::2]) / 2) and torch.allclose(out[:, 1::2], (lr[:, 1::2] - lr[:, 0::2]) / 2)
+
+
+def _world1_worker(port, out_q):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1")
+    dist.init_process_group("gloo", rank=0, world_size=1)
+    try:
+        from marconet_amd.pipeline import OverlappedGather, all_gather_outputs
+        local = torch.stack([_fake_sr(i) for i in range(3)])
+        same = all_gather_outputs(local, 3)                       # no collective in a world of one ...
+        forced = all_gather_outputs(local, 3, force=True)         # ... unless forced: a new tensor, equal content
+        og = OverlappedGather()
+        first = og.submit(local)
+        out_q.put((same is local, forced is not local and bool(torch.equal(forced, local)), first is None and bool(torch.equal(og.flush(), local))))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_forced_collective_in_a_world_of_one_gloo():
+    """the switch the 1-GPU RCCL test uses (tests/test_multigpu_gpu.py::test_rccl_path_runs_in_a_world_of_one)"""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_world1_worker, args=(_free_port(), q))
+    p.start()
+    res = q.get(timeout=120)
+    p.join(timeout=60)
+    assert res == (True, True, True)

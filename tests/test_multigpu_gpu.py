@@ -1,5 +1,7 @@
-"""-m gpu, needs >= 2 visible MI355X (skipped on the 1-GPU box): N-GPU gathered output == 1-GPU output, bit for bit, through
-the real pipeline over RCCL (SURVEY.md §8e correctness test)."""
+"""-m gpu: N-GPU gathered output == 1-GPU output, bit for bit, through the real pipeline over RCCL (SURVEY.md §8e correctness
+test).  The 2-rank form needs >= 2 visible MI355X (skipped on the 1-GPU box); the WORLD_SIZE=1 form runs the same worker with
+force_collective, so that init_process_group("nccl"), all_gather_into_tensor on device buffers and OverlappedGather's stream
+ordering execute on the hardware that is there."""
 import json
 import os
 import socket
@@ -38,3 +40,17 @@ def test_sharded_forward_equals_single_gpu(total, tmp_path):
     assert res["world"] == world and res["backend"] == "nccl"
     for k in ("fp32.u8_bgr", "fp32.nchw_f32", "fp16x3.u8_bgr", "fp16x3.nchw_f32", "fp16.u8_bgr", "fp16.nchw_f32"):
         assert res[k], "%s: gathered result differs from the single-GPU result" % k
+
+
+def test_rccl_path_runs_in_a_world_of_one(tmp_path):
+    """init_process_group("nccl") + all_gather_into_tensor + OverlappedGather on ONE MI355X (world size 1, collectives forced)"""
+    port, out = _free_port(), str(tmp_path / "res1.json")
+    env = dict(os.environ, RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+               HSA_ENABLE_IPC_MODE_LEGACY="0")
+    p = subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "dist_pipeline_worker.py"), out, "4", "force"], env=env)
+    assert p.wait(timeout=900) == 0
+    res = json.load(open(out))
+    assert res["world"] == 1 and res["backend"] == "nccl"
+    for k in ("fp32.u8_bgr", "fp32.nchw_f32", "fp16x3.u8_bgr", "fp16x3.nchw_f32", "fp16.u8_bgr", "fp16.nchw_f32",
+              "fp32.overlapped", "fp16x3.overlapped", "fp16.overlapped"):
+        assert res[k], "%s: result through the forced collective differs from forward_batch" % k
