@@ -36,6 +36,7 @@ sys.path.insert(0, ROOT)
 PEAK_F16_TFLOPS = 2500.0       # MI355X dense fp16 MFMA (MI355X_MICROARCH.md)
 PEAK_F32_TFLOPS = 157.3        # fp32 matrix (v_mfma_f32_16x16x4_f32)
 PEAK_F16X3_TFLOPS = PEAK_F16_TFLOPS / 3.0    # split-precision: three fp16 MFMA products per algorithmic product
+PEAK_F16X2_TFLOPS = PEAK_F16_TFLOPS / 2.0    # fp16+8: one fp16 MFMA product + both corrections as one fp8 MFMA (twice the rate, twice the k): 2 units
 GF_RESNET, GF_VIT, GF_SR_TRUNK = 108.01, 3.69, 484.12     # GFLOP / image
 GF_GAN, GF_SR_PRIOR = 41.78, 47.25                         # GFLOP / glyph
 GF_F16_FIXED = GF_RESNET + GF_SR_TRUNK
@@ -51,13 +52,19 @@ KNAME = {1: "conv_igemm_kernel (register-staged)", 3: "conv_skinny_f32_kernel", 
 KNAME_X3 = {33: "conv_strip_kernel<64,512,1,8,x3>", 22: "conv_dma_kernel<256,256,2,4,2,16>", 23: "conv_dma_kernel<128,512,2,4,2,16>",      # split-half ids 6 / 7: the 8-wave tiles
             24: "conv_dma_kernel<256,256,2,4,2,16,spread>", 25: "conv_dma_kernel<128,512,2,4,2,16,spread>",
             27: "conv_dma_kernel<256,256,2,4,2,16,spread,pipe>", 28: "conv_dma_kernel<128,512,2,4,2,16,spread,pipe>"}
-DTNAME = {0: "f32", 1: "f16", 2: "f16x3"}
+KNAME_X2 = {16: "conv_dma_kernel<256,256,4,4,2,32,mx>", 17: "conv_dma_kernel<256,128,4,2,3,32,mx>", 18: "conv_dma_kernel<128,256,2,4,3,32,mx>",
+            19: "conv_dma_kernel<64,256,1,8,3,32,mx>", 20: "conv_dma_kernel<128,512,2,8,2,32,mx>", 21: "conv_dma_kernel<64,512,1,8,2,32,mx>",
+            22: "conv_dma_kernel<256,256,2,4,2,32,mx>", 23: "conv_dma_kernel<128,512,2,4,2,32,mx>", 24: "conv_dma_kernel<128,512,1,8,2,32,mx>",
+            26: "conv_dma_kernel<128,128,2,4,4,32,mx>"}
+DTNAME = {0: "f32", 1: "f16", 2: "f16x3", 3: "f16x2"}
+MFMA_UNITS = {0: 1.0, 1: 1.0, 2: 3.0, 3: 2.0}      # fp16-MFMA-equivalent time units per algorithmic product
 
 
 def kname(kid, dt):
-    return (KNAME_X3.get(kid) if dt == 2 else None) or KNAME.get(kid, str(kid))
+    return (KNAME_X3.get(kid) if dt == 2 else KNAME_X2.get(kid) if dt == 3 else None) or KNAME.get(kid, str(kid))
 
-DTPEAK = {0: PEAK_F32_TFLOPS, 1: PEAK_F16_TFLOPS, 2: PEAK_F16X3_TFLOPS}
+DTPEAK = {0: PEAK_F32_TFLOPS, 1: PEAK_F16_TFLOPS, 2: PEAK_F16X3_TFLOPS, 3: PEAK_F16X2_TFLOPS}
+PDT = {"fp32": 0, "fp16": 1, "fp16x3": 2, "fp16x2": 3}
 # sources whose content decides the dominant kernel's HBM traffic: the PMC figure in profiles/pmc_traffic.json is reported
 # only while these files are the ones it was measured on (else it is stale and `traffic` is null)
 KERNEL_SOURCES = ["marconet_amd/csrc/conv_igemm_dma.hip", "marconet_amd/csrc/conv_dma_common.h", "marconet_amd/csrc/conv_args.h"]
@@ -79,9 +86,12 @@ def parse():
     ap.add_argument("--config", default="sr", choices=["sr", "gan", "mixed"], help="sr: the headline path; gan: configs[3]; mixed: configs[4]")
     ap.add_argument("--batch", type=int, default=256, help="images per GPU (the metric's batch 256; configs[1]: 64; configs[2]: 128 on 8 GPUs)")
     ap.add_argument("--glyphs", type=int, default=16, help="glyphs per image (SURVEY.md §8d: n=16)")
-    ap.add_argument("--precision", default="fp16x3", choices=["fp16x3", "fp16", "fp32"],
-                    help="fp16x3 (default): split-half storage, the throughput mode that meets the 1e-3 parity bar; fp16: BASELINE configs[1]'s "
-                         "storage type (reported as a secondary figure with its measured deviation); fp32: exact fp32 MFMA")
+    ap.add_argument("--precision", default="fp16x2", choices=["fp16x2", "fp16x3", "fp16", "fp32"],
+                    help="fp16x2 (default): fp16+8 storage, x*w = hi*hi on the f16 MFMA + one block-scaled fp8 MFMA for both correction products — "
+                         "the fastest mode that meets the 1e-3 parity bar; fp16x3: split-half storage (three f16 MFMA products, fp32-class accuracy); "
+                         "fp16: BASELINE configs[1]'s storage type (secondary figure with its measured deviation); fp32: exact fp32 MFMA")
+    ap.add_argument("--force-gather", action="store_true", help="N=1: initialise an RCCL process group of one rank and run the output "
+                                                                 "all-gather inside the timed region anyway (its cost is reported)")
     ap.add_argument("--cpu-images", type=int, default=4, help="images timed on the host CPU oracle (0 = skip); ~3.5 s each on 32 threads")
     ap.add_argument("--no-secondary", action="store_true", help="skip the secondary throughput measurements")
     ap.add_argument("--cpu-threads", type=int, default=32, help="cap on host threads for the CPU baseline")
@@ -138,7 +148,7 @@ def conv_roofline(ops, steps, alg_gf_step, prefer_dtype, batch=None, precision=N
     if os.path.isfile(tpath):
         try:
             tj = json.load(open(tpath))
-            ent = tj.get(kn + (" " + DTNAME[dom[1]] if dom[1] == 2 else ""), {})
+            ent = tj.get(kn + (" " + DTNAME[dom[1]] if dom[1] >= 2 else ""), {})
             if tj.get("kernel_sources_sha16") == kernel_sources_sha() and tj.get("batch") == batch and tj.get("precision") == precision:
                 traffic = ent.get("hbm_bytes_per_launch")
                 traffic_note = "rocprofv3 --pmc passes of this bench at %s (profiles/%s), kernel sources unchanged since" % (tj.get("measured_at", "?"), os.path.basename(tpath))
@@ -149,7 +159,11 @@ def conv_roofline(ops, steps, alg_gf_step, prefer_dtype, batch=None, precision=N
             traffic_note = "profiles/%s unreadable: %s" % (os.path.basename(tpath), e)
     return {
         "bound": "mfma", "achieved": round(achieved, 2), "peak": round(peak, 1), "unit": "TFLOP/s",
-        "frac": round(achieved / peak, 4), "traffic": traffic, "traffic_source": traffic_note,
+        "frac": round(achieved / peak, 4), "frac_of_fp16_dense": round(achieved / PEAK_F16_TFLOPS, 4),
+        "executed_mfma_tflops": round(achieved * MFMA_UNITS[dom[1]], 1),
+        "peak_note": "peak = 2500 TFLOP/s dense fp16 MFMA / %.0f fp16-MFMA time units per algorithmic product in this mode; executed_mfma_tflops = "
+                     "achieved x units (fp16-equivalent matrix-pipe work), frac_of_fp16_dense = achieved / 2500" % MFMA_UNITS[dom[1]],
+        "traffic": traffic, "traffic_source": traffic_note,
         "kernel": kn + " " + DTNAME[dom[1]],
         "launches_per_step": dom_n // max(steps, 1),
         "avg_launch_ms": round(dom_ms / max(dom_n, 1), 4),
@@ -177,8 +191,13 @@ def main():
     import torch.distributed as dist
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    if world > 1:
+    if world > 1 or a.force_gather:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        if world == 1:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29533")
+            os.environ.setdefault("RANK", "0")
+            os.environ.setdefault("WORLD_SIZE", "1")
         dist.init_process_group("nccl", device_id=dev)
         # N ranks build the same seeded checkpoints on the host at the same time: do not oversubscribe its cores
         torch.set_num_threads(max(1, min(32, host_threads(1 << 30) // world)))
@@ -191,11 +210,12 @@ def main():
     enc.load_state_dict(sde, strict=True)
     gan.load_state_dict(sdg, strict=True)
     sr.load_state_dict(sds, strict=True)
-    pipe = MarconetPipeline(enc.eval().to(dev), gan.eval().to(dev), sr.eval().to(dev), precision=a.precision, check_finite=False)
-    pdt = {"fp32": 0, "fp16": 1, "fp16x3": 2}[a.precision]
+    # the product's defaults (check_finite included: on for the half-range modes, one flag read back per batch)
+    pipe = MarconetPipeline(enc.eval().to(dev), gan.eval().to(dev), sr.eval().to(dev), precision=a.precision)
+    pdt = PDT[a.precision]
 
     B, n = a.batch, a.glyphs
-    gather = OverlappedGather() if world > 1 and not a.no_gather and a.config != "gan" else None
+    gather = OverlappedGather() if (world > 1 or a.force_gather) and not a.no_gather and a.config != "gan" else None
     u8 = gather is not None and a.gather_format == "u8"
 
     def fence():
@@ -269,9 +289,13 @@ def main():
 
     for _ in range(a.warmup):
         step()
-    ops.stats.reset()
-    ops.stats.enabled = ops.stats.timing = True          # HIP events around every conv launch (same stream)
+    # headline: the product's default configuration, un-instrumented
     dt, per_rank_dt, y = timed(step, fence, a.steps, world, dev)
+    # roofline of the dominant kernel: a SEPARATE pass with HIP events around every conv launch (same stream)
+    prof_steps = min(a.steps, 2)
+    ops.stats.reset()
+    ops.stats.enabled = ops.stats.timing = True
+    timed(step, fence, prof_steps, world, dev)
     ops.stats.enabled = ops.stats.timing = False
     if y.dtype.is_floating_point:
         assert torch.isfinite(y).all()
@@ -282,7 +306,8 @@ def main():
         dist.all_gather(allc, t)
         per_rank_images = [int(v.item()) for v in allc]
         total_images = sum(per_rank_images)
-    roofline, peak = conv_roofline(ops, a.steps, alg_gf_step, pdt, B if a.config == "sr" else None, a.precision)
+    roofline, peak = conv_roofline(ops, prof_steps, alg_gf_step, pdt, B if a.config == "sr" else None, a.precision)
+    roofline["measured_in"] = "a separate instrumented pass of %d step(s) after the timed region (HIP events around every conv launch)" % prof_steps
 
     # ---- secondary figures (reported separately, never the headline)
     if a.config == "sr" and not a.no_secondary:
@@ -295,7 +320,7 @@ def main():
                      "note": "opt-in MarconetPipeline(need_prior_image=False): TSPGAN stops at the 64-px level; SR output identical"}
         # the other precision modes on the same batch (fp32: a 16-image slice — 54 images/s): the mode that meets the parity bar
         # (fp16x3, or fp32) is always reported next to the fp16 storage mode, with its measured deviation under "parity" below
-        for prec in ("fp16x3", "fp16", "fp32"):
+        for prec in ("fp16x2", "fp16x3", "fp16", "fp32"):
             if prec == a.precision:
                 continue
             pipe.set_precision(prec)
@@ -307,14 +332,20 @@ def main():
             secondary["%s_mode_images_per_s" % prec] = round((total_images if kk == B else kk * world) * n_steps / dtk, 3)
             secondary["%s_mode_batch_per_gpu" % prec] = kk
         # a point in between: only the encoder (5 % of the FLOPs; its style vector w feeds every modulation) in the split-half mode
-        pipe.set_precision("fp16")
-        pipe.encoder.set_precision("fp16x3")
-        step()
-        dtm, _, _ = timed(step, fence, a.steps, world, dev)
-        secondary["fp16_with_fp16x3_encoder_images_per_s"] = round(total_images * a.steps / dtm, 3)
         pipe.set_precision(a.precision)
-        secondary["modes"] = ("fp32: exact fp32 MFMA (parity mode); fp16x3: split-half storage, hi*hi + hi*lo + lo*hi on the fp16 MFMA "
+        secondary["modes"] = ("fp32: exact fp32 MFMA (parity mode); fp16x3: split-half storage, hi*hi + hi*lo + lo*hi on the fp16 MFMA (fp32-class "
+                              "accuracy); fp16x2: fp16+8 storage, hi*hi on the f16 MFMA + one block-scaled fp8 MFMA for both correction products "
                               "(meets the 1e-3 bar, see parity); fp16: one half per element (BASELINE configs[1]'s storage type)")
+        if gather is not None and world == 1:
+            # --force-gather: what the collective costs when nothing hides it (a world of one: the gather is a device copy through RCCL)
+            pipe_y = step()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(5):
+                gather.submit(pipe_y)
+                gather.flush()
+            torch.cuda.synchronize()
+            secondary["forced_all_gather_ms"] = round((time.perf_counter() - t0) / 5 * 1e3, 3)
 
     out = {
         "metric": {"sr": "SR images/sec (32x512 LR -> 128x2048 SR)", "gan": "TSPGAN glyph images/sec (128x128 structure prior)",
@@ -325,19 +356,20 @@ def main():
         "vs_baseline": None, "dtype": DTNAME[pdt], "data": "synthetic",
         "config": {"workload": workload, "per_gpu_batch": B, "global_batch": total_images, "glyphs_per_image": n,
                    "parallelism": "dp%d" % world,
-                   "collective": ("all_gather(%s), asynchronous, overlapped with the next step"
+                   "collective": (("RCCL world of %d: " % world) + "all_gather(%s), asynchronous, overlapped with the next step"
                                   % ("uint8 BGR post-processed SR [b,128,2048,3]" if u8 else "fp32 SR outputs [b,3,128,2048]"))
                    if gather is not None else "none"},
         "roofline": roofline,
         "secondary": secondary,
     }
     if a.config == "sr":
-        out["headline_note"] = ("value is measured in the %s precision mode. fp16x3 (split-half storage, hi*hi + hi*lo + lo*hi on the fp16 MFMA) is the "
-                                "throughput mode that meets the north-star parity bar (<= 1e-3, indices bit-exact; see parity); the plain fp16 "
-                                "storage mode — BASELINE configs[1]'s type and round 1's headline, ~1e-2 deviation — is secondary.fp16_mode_images_per_s, "
-                                "the exact fp32 mode secondary.fp32_mode_images_per_s" % a.precision)
+        out["headline_note"] = ("value is measured in the %s precision mode, in the product's default configuration (check_finite on), un-instrumented. "
+                                "fp16x2 (fp16+8 storage: hi*hi on the f16 MFMA + w_lo8*x_hi8 + w_hi8*x_lo8 as one block-scaled fp8 MFMA) and fp16x3 "
+                                "(split-half storage, three f16 MFMA products) both meet the north-star parity bar (<= 1e-3, indices bit-exact; see "
+                                "parity); the plain fp16 storage mode — BASELINE configs[1]'s type, ~1e-2 deviation — and the exact fp32 mode are "
+                                "secondary.*_mode_images_per_s" % a.precision)
     roofline["end_to_end_frac_of_peak"] = round(out["value"] / world * gf_image / 1e3 / peak, 4)
-    if world > 1:
+    if world > 1 or a.force_gather:
         out["ranks"] = {"world_size": dist.get_world_size(), "backend": dist.get_backend(),
                         "per_rank_images_per_s": [round(c_ * a.steps / t_, 2) for c_, t_ in zip(per_rank_images, per_rank_dt)]}
 
@@ -358,10 +390,21 @@ def main():
         out["cpu_baseline"] = {"value": round(k / cdt, 4), "unit": "images/s", "cores": threads, "kind": "port",
                                "sample": "%d images (batch 1 each, %d glyphs) of the same workload through oracle/marconet_oracle.py, "
                                          "torch %s CPU fp32, %d threads" % (k, n, torch.__version__, threads)}
+        # the same at batch 8 (one call) and per network (seconds per image at batch 1)
+        k8 = min(8, B)
+        if k8 > 1:
+            t0 = time.perf_counter()
+            O.end_to_end(sde, sdg, sds, lq[:k8].cpu(), labels[:k8], locs[:k8])
+            out["cpu_baseline"]["batch8_images_per_s"] = round(k8 / (time.perf_counter() - t0), 4)
+        with torch.no_grad():
+            t0 = time.perf_counter(); lg_, _, w_ = O.encoder_forward(sde, lq_c[:1]); t_enc = time.perf_counter() - t0
+            t0 = time.perf_counter(); g_ = O.tspgan_forward(sdg, w_[:1].repeat(lab_c[0].shape[0], 1), lab_c[0]); t_gan = time.perf_counter() - t0
+            t0 = time.perf_counter(); O.tspsr_forward(sds, lq_c[:1], [g_[1]], [g_[2]], locs_c[:1]); t_sr = time.perf_counter() - t0
+        out["cpu_baseline"]["seconds_per_image_by_net"] = {"encoder": round(t_enc, 3), "tspgan_%d_glyphs" % n: round(t_gan, 3), "tspsrnet": round(t_sr, 3)}
         ref_sr = torch.cat([r["sr"] for r in refs])
         ref_arg = torch.cat([r["logits"] for r in refs]).argmax(-1)
         par = {}
-        for prec in ("fp16", "fp16x3", "fp32"):
+        for prec in ("fp16", "fp16x2", "fp16x3", "fp32"):
             try:
                 pipe.set_precision(prec)
             except ValueError:
@@ -370,12 +413,6 @@ def main():
             lg = pipe.encoder(lq[:k])[0]
             par["sr_max_abs_%s" % prec] = round((yk.cpu() - ref_sr).abs().max().item(), 6)
             par["argmax_match_%s" % prec] = round(float((lg.argmax(-1).cpu() == ref_arg).float().mean()), 4)
-        pipe.set_precision("fp16")
-        pipe.encoder.set_precision("fp16x3")
-        yk = pipe.forward_batch(lq[:k], labels[:k], locs[:k])
-        lg = pipe.encoder(lq[:k])[0]
-        par["sr_max_abs_fp16_with_fp16x3_encoder"] = round((yk.cpu() - ref_sr).abs().max().item(), 6)
-        par["argmax_match_fp16_with_fp16x3_encoder"] = round(float((lg.argmax(-1).cpu() == ref_arg).float().mean()), 4)
         pipe.set_precision(a.precision)
         par["bar"] = "north_star: <= 1e-3 max-abs on the SR output, argmax bit-exact (argmax_match == 1.0)"
         out["parity"] = par
@@ -397,7 +434,7 @@ def main():
 
     if rank == 0:
         print(json.dumps(out))
-    if world > 1:
+    if dist.is_initialized():
         dist.destroy_process_group()
 
 

@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define MNET_ABI_VERSION 2
+#define MNET_ABI_VERSION 3
 
 /* MNET_F16X2 ("split half", the storage of the fp16x3 precision mode): every logical element is a pair of halves (hi, lo),
  * value = float(hi) + float(lo), hi = f16(v), lo = f16(v - hi): ~22 significant bits at fp16 MFMA rates (x*w is evaluated as
@@ -34,7 +34,16 @@ extern "C" {
  * C % 32 == 0 and a 128-byte aligned base: per pixel 4*C bytes in blocks of 32 channels, 64 bytes of hi followed by 64 bytes
  * of lo.  Conv weights [cout][kh][kw][cin] use the same blocking along cin and hold hi/lo of 256*W (the conv multiplies its
  * accumulator by 2^-8).  Entry points that accept it say so; sizes/strides are always given in LOGICAL elements. */
-typedef enum { MNET_F32 = 0, MNET_F16 = 1, MNET_F16X2 = 2 } mnet_dtype;
+/* MNET_F16M ("fp16+8", the storage of the fp16x2 precision mode): the same 4 bytes per logical element and the same blocking
+ * (128 bytes per (pixel, 32-channel block), C % 32 == 0, 128-byte aligned base), but only the hi part is a half; the lo part is an
+ * OCP e4m3 byte under one E8M0 scale per block, so that x*w = hi*hi on the f16 MFMA + (w_lo8*x_hi8 + w_hi8*x_lo8) as ONE block-scaled
+ * fp8 MFMA (v_mfma_scale_f32_32x32x64_f8f6f4, twice the f16 rate): 2 MFMA units per product instead of 3, ~16 significant bits.
+ *   activations  bytes 0-63 hi = f16(v) of channels 0..31 | 64-95 lo8 = e4m3((v - hi) * 2^11 / s), channel order 0-7,16-23,8-15,24-31 |
+ *                byte 96 E: s = 2^(E-127) = 2^(floor(log2 max|hi|) - 7) | bytes 97-127 zero
+ *   conv weights bytes 0-63 hi = f16(256 W) | 64-79 lo8 of channels 0-7,16-23 | 80-95 hi8 = e4m3(hi / s) of the same | 96-111 lo8 of
+ *                8-15,24-31 | 112-127 hi8 of the same; s per OUTPUT channel; after the cout*kh*kw*cin elements one byte per output
+ *                channel (E8M0 of s * 2^-11), i.e. a packed weight tensor is cout*kh*kw*cin*4 + cout bytes (mnet_pack_weights). */
+typedef enum { MNET_F32 = 0, MNET_F16 = 1, MNET_F16X2 = 2, MNET_F16M = 3 } mnet_dtype;
 
 typedef enum {
     MNET_ACT_NONE = 0,

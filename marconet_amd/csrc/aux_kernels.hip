@@ -5,6 +5,8 @@
 // wave64 butterflies, no atomics (results are bit-reproducible run to run).
 #include "common.h"
 
+static inline bool is_split4(int dt) { return dt == MNET_F16X2 || dt == MNET_F16M; }      // the two 4-byte blocked storages
+
 // ============================================================================ layout: NCHW fp32 <-> NHWC T
 template <typename T>
 __global__ void __launch_bounds__(256) nchw_to_nhwc_kernel(const float* __restrict__ src, T* __restrict__ dst,
@@ -22,7 +24,11 @@ __global__ void __launch_bounds__(256) nchw_to_nhwc_kernel(const float* __restri
     T* d = dst + (size_t)n * HW * Cld;
     for (int j = ty; j < 32; j += 8) {
         const int p = p0 + j, c = c0 + tx;
-        if (p < HW && c < Cld) st_elem<T>(d + (size_t)p * Cld, c, tile[tx][j]);
+        if constexpr (__is_same(T, hm)) {
+            if (p < HW) st_block32_hm(d + (size_t)p * Cld, c, tile[tx][j]);      // Cld % 32 == 0: the 32 lanes tx are one block
+        } else {
+            if (p < HW && c < Cld) st_elem<T>(d + (size_t)p * Cld, c, tile[tx][j]);
+        }
     }
 }
 
@@ -48,14 +54,15 @@ __global__ void __launch_bounds__(256) nhwc_to_nchw_kernel(const T* __restrict__
 extern "C" int mnet_nchw_to_nhwc(const float* src, void* dst, int32_t dst_dtype, int32_t n, int32_t c, int32_t h,
                                  int32_t w, int32_t c_ld, void* stream) {
     MNET_CHECK_ARG(src && dst && n > 0 && c > 0 && h > 0 && w > 0 && c_ld >= c, "nchw_to_nhwc: bad args");
-    MNET_CHECK_ARG(dst_dtype == MNET_F32 || dst_dtype == MNET_F16 || dst_dtype == MNET_F16X2, "nchw_to_nhwc: bad dtype");
-    MNET_CHECK_ALIGN(dst_dtype != MNET_F16X2 || (c_ld % 32 == 0 && aligned128(dst)), "nchw_to_nhwc: split-half output needs c_ld %% 32 == 0 and a 128-byte aligned base");
+    MNET_CHECK_ARG(dst_dtype == MNET_F32 || dst_dtype == MNET_F16 || is_split4(dst_dtype), "nchw_to_nhwc: bad dtype");
+    MNET_CHECK_ALIGN(!is_split4(dst_dtype) || (c_ld % 32 == 0 && aligned128(dst)), "nchw_to_nhwc: split-half output needs c_ld %% 32 == 0 and a 128-byte aligned base");
     MNET_CHECK_ARG(n <= 65535 && (c_ld + 31) / 32 <= 65535, "nchw_to_nhwc: grid too large");
     const int HW = h * w;
     dim3 grid((HW + 31) / 32, (c_ld + 31) / 32, n), block(32, 8);
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     if (dst_dtype == MNET_F16) hipLaunchKernelGGL(nchw_to_nhwc_kernel<f16>, grid, block, 0, st, src, (f16*)dst, c, HW, c_ld);
     else if (dst_dtype == MNET_F16X2) hipLaunchKernelGGL(nchw_to_nhwc_kernel<hs>, grid, block, 0, st, src, (hs*)dst, c, HW, c_ld);
+    else if (dst_dtype == MNET_F16M) hipLaunchKernelGGL(nchw_to_nhwc_kernel<hm>, grid, block, 0, st, src, (hm*)dst, c, HW, c_ld);
     else hipLaunchKernelGGL(nchw_to_nhwc_kernel<float>, grid, block, 0, st, src, (float*)dst, c, HW, c_ld);
     MNET_LAUNCH_CHECK("nchw_to_nhwc");
     return MNET_OK;
@@ -64,14 +71,15 @@ extern "C" int mnet_nchw_to_nhwc(const float* src, void* dst, int32_t dst_dtype,
 extern "C" int mnet_nhwc_to_nchw(const void* src, int32_t src_dtype, float* dst, int32_t n, int32_t c, int32_t h,
                                  int32_t w, int32_t c_ld, void* stream) {
     MNET_CHECK_ARG(src && dst && n > 0 && c > 0 && h > 0 && w > 0 && c_ld >= c, "nhwc_to_nchw: bad args");
-    MNET_CHECK_ARG(src_dtype == MNET_F32 || src_dtype == MNET_F16 || src_dtype == MNET_F16X2, "nhwc_to_nchw: bad dtype");
-    MNET_CHECK_ALIGN(src_dtype != MNET_F16X2 || (c_ld % 32 == 0 && aligned128(src)), "nhwc_to_nchw: split-half input needs c_ld %% 32 == 0 and a 128-byte aligned base");
+    MNET_CHECK_ARG(src_dtype == MNET_F32 || src_dtype == MNET_F16 || is_split4(src_dtype), "nhwc_to_nchw: bad dtype");
+    MNET_CHECK_ALIGN(!is_split4(src_dtype) || (c_ld % 32 == 0 && aligned128(src)), "nhwc_to_nchw: split-half input needs c_ld %% 32 == 0 and a 128-byte aligned base");
     MNET_CHECK_ARG(n <= 65535 && (c + 31) / 32 <= 65535, "nhwc_to_nchw: grid too large");
     const int HW = h * w;
     dim3 grid((HW + 31) / 32, (c + 31) / 32, n), block(32, 8);
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     if (src_dtype == MNET_F16) hipLaunchKernelGGL(nhwc_to_nchw_kernel<f16>, grid, block, 0, st, (const f16*)src, dst, c, HW, c_ld);
     else if (src_dtype == MNET_F16X2) hipLaunchKernelGGL(nhwc_to_nchw_kernel<hs>, grid, block, 0, st, (const hs*)src, dst, c, HW, c_ld);
+    else if (src_dtype == MNET_F16M) hipLaunchKernelGGL(nhwc_to_nchw_kernel<hm>, grid, block, 0, st, (const hm*)src, dst, c, HW, c_ld);
     else hipLaunchKernelGGL(nhwc_to_nchw_kernel<float>, grid, block, 0, st, (const float*)src, dst, c, HW, c_ld);
     MNET_LAUNCH_CHECK("nhwc_to_nchw");
     return MNET_OK;
@@ -142,16 +150,17 @@ __global__ void __launch_bounds__(256) upsample2x_kernel(const T* __restrict__ s
 extern "C" int mnet_upsample2x_scale_nhwc(const void* src, void* dst, int32_t dtype, int32_t n, int32_t h, int32_t w,
                                           int32_t c, const float* scale, void* stream) {
     MNET_CHECK_ARG(src && dst && n > 0 && h > 0 && w > 0 && c > 0 && n <= 65535, "upsample2x: bad args");
-    MNET_CHECK_ARG(dtype == MNET_F32 || dtype == MNET_F16 || dtype == MNET_F16X2, "upsample2x: bad dtype");
+    MNET_CHECK_ARG(dtype == MNET_F32 || dtype == MNET_F16 || is_split4(dtype), "upsample2x: bad dtype");
     const int N = dtype == MNET_F32 ? 4 : 8;
     MNET_CHECK_ALIGN(c % N == 0 && aligned16(src) && aligned16(dst) && aligned16(scale), "upsample2x: c %% %d != 0 or unaligned", N);
-    MNET_CHECK_ALIGN(dtype != MNET_F16X2 || (c % 32 == 0 && aligned128(src) && aligned128(dst)), "upsample2x: split-half needs c %% 32 == 0, 128-byte aligned");
+    MNET_CHECK_ALIGN(!is_split4(dtype) || (c % 32 == 0 && aligned128(src) && aligned128(dst)), "upsample2x: split-half needs c %% 32 == 0, 128-byte aligned");
     const long long per = (long long)h * w * (c / N);             // one thread per input chunk
     MNET_CHECK_ARG(per * 4 < (1ll << 31), "upsample2x: image too large");
     const int gx = (int)((per + 255) / 256 < 2048 ? (per + 255) / 256 : 2048);
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     if (dtype == MNET_F16) hipLaunchKernelGGL(upsample2x_kernel<f16>, dim3(gx, n), dim3(256), 0, st, (const f16*)src, (f16*)dst, h, w, c, scale, (unsigned)per);
     else if (dtype == MNET_F16X2) hipLaunchKernelGGL(upsample2x_kernel<hs>, dim3(gx, n), dim3(256), 0, st, (const hs*)src, (hs*)dst, h, w, c, scale, (unsigned)per);
+    else if (dtype == MNET_F16M) hipLaunchKernelGGL(upsample2x_kernel<hm>, dim3(gx, n), dim3(256), 0, st, (const hm*)src, (hm*)dst, h, w, c, scale, (unsigned)per);
     else hipLaunchKernelGGL(upsample2x_kernel<float>, dim3(gx, n), dim3(256), 0, st, (const float*)src, (float*)dst, h, w, c, scale, (unsigned)per);
     MNET_LAUNCH_CHECK("upsample2x");
     return MNET_OK;
@@ -231,13 +240,14 @@ extern "C" int mnet_groupnorm_affine(const void* x, int32_t dtype, int32_t n, in
                                      double* partial, int32_t slices, float* scale, float* shift, void* stream) {
     MNET_CHECK_ARG(x && gamma && beta && partial && scale && shift, "groupnorm: null pointer");
     MNET_CHECK_ARG(n > 0 && h > 0 && w > 0 && c > 0 && slices > 0 && n <= 65535, "groupnorm: bad geometry");
-    MNET_CHECK_ARG(dtype == MNET_F32 || dtype == MNET_F16 || dtype == MNET_F16X2, "groupnorm: bad dtype");
+    MNET_CHECK_ARG(dtype == MNET_F32 || dtype == MNET_F16 || is_split4(dtype), "groupnorm: bad dtype");
     const int N = dtype == MNET_F32 ? 4 : 8;
     MNET_CHECK_ALIGN(c % 32 == 0 && 256 % (c / N) == 0 && aligned16(x), "groupnorm: c=%d unsupported", c);
-    MNET_CHECK_ALIGN(dtype != MNET_F16X2 || aligned128(x), "groupnorm: split-half tensors must be 128-byte aligned");
+    MNET_CHECK_ALIGN(!is_split4(dtype) || aligned128(x), "groupnorm: split-half tensors must be 128-byte aligned");
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     if (dtype == MNET_F16) hipLaunchKernelGGL(gn_partial_kernel<f16>, dim3(slices, n), dim3(256), 0, st, (const f16*)x, h, w, c, valid_w, partial, slices);
     else if (dtype == MNET_F16X2) hipLaunchKernelGGL(gn_partial_kernel<hs>, dim3(slices, n), dim3(256), 0, st, (const hs*)x, h, w, c, valid_w, partial, slices);
+    else if (dtype == MNET_F16M) hipLaunchKernelGGL(gn_partial_kernel<hm>, dim3(slices, n), dim3(256), 0, st, (const hm*)x, h, w, c, valid_w, partial, slices);
     else hipLaunchKernelGGL(gn_partial_kernel<float>, dim3(slices, n), dim3(256), 0, st, (const float*)x, h, w, c, valid_w, partial, slices);
     MNET_LAUNCH_CHECK("gn_partial");
     const int tot = n * c;
@@ -360,19 +370,23 @@ static int adain_launch(const void* prior, const void* feat, void* out, int32_t 
                         const float* gamma, const float* beta, float eps, float* scale, float* shift, void* stream) {
     MNET_CHECK_ARG(prior && feat && out && g_img && g_x1 && g_y1 && g_w, "adain: null pointer");
     MNET_CHECK_ARG(G > 0 && S > 0 && C > 0 && feat_w >= S, "adain: bad geometry");
-    MNET_CHECK_ARG(dtype == MNET_F32 || dtype == MNET_F16 || dtype == MNET_F16X2, "adain: bad dtype");
+    MNET_CHECK_ARG(dtype == MNET_F32 || dtype == MNET_F16 || is_split4(dtype), "adain: bad dtype");
     const int N = dtype == MNET_F32 ? 4 : 8;
     MNET_CHECK_ALIGN(C % N == 0 && 256 % (C / N) == 0 && C % 32 == 0 && aligned16(prior) && aligned16(feat) && aligned16(out),
                      "adain: C=%d unsupported or unaligned", C);
-    MNET_CHECK_ALIGN(dtype != MNET_F16X2 || (aligned128(prior) && aligned128(feat) && aligned128(out)), "adain: split-half tensors must be 128-byte aligned");
+    MNET_CHECK_ALIGN(!is_split4(dtype) || (aligned128(prior) && aligned128(feat) && aligned128(out)), "adain: split-half tensors must be 128-byte aligned");
     const size_t lds = (size_t)256 * N * 4 * sizeof(double) + (size_t)4 * C * sizeof(float) + (size_t)4 * C * sizeof(double) +
                        (size_t)(2 * C / 32) * 2 * sizeof(float);
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-    static thread_local size_t lds_all[256][3] = {};                   // attribute raised once per (device, size) (not during graph capture replays)
+    static thread_local size_t lds_all[256][4] = {};                   // attribute raised once per (device, size) (not during graph capture replays)
     size_t* lds_set = lds_all[DeviceOnce::dev()];
     if (dtype == MNET_F16X2) {
         if (lds > lds_set[2]) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(adain_crop_kernel<hs>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); lds_set[2] = lds; }
         hipLaunchKernelGGL(adain_crop_kernel<hs>, dim3(G), dim3(256), lds, st, (const hs*)prior, (const hs*)feat, (hs*)out, S, C, feat_w,
+                           g_img, g_x1, g_y1, g_w, gamma, beta, eps, scale, shift);
+    } else if (dtype == MNET_F16M) {
+        if (lds > lds_set[3]) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(adain_crop_kernel<hm>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); lds_set[3] = lds; }
+        hipLaunchKernelGGL(adain_crop_kernel<hm>, dim3(G), dim3(256), lds, st, (const hm*)prior, (const hm*)feat, (hm*)out, S, C, feat_w,
                            g_img, g_x1, g_y1, g_w, gamma, beta, eps, scale, shift);
     } else if (dtype == MNET_F16) {
         if (lds > lds_set[1]) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(adain_crop_kernel<f16>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); lds_set[1] = lds; }
@@ -552,8 +566,8 @@ extern "C" int mnet_adain_crop_concat_split(const void* prior, const void* feat,
                                             double* partial, float* stat, int32_t slices, void* stream) {
     MNET_CHECK_ARG(prior && feat && out && g_img && g_x1 && g_y1 && g_w && partial && stat, "adain_split: null pointer");
     MNET_CHECK_ARG(G > 0 && G <= 65535 && S > 0 && C > 0 && feat_w >= S && slices > 0 && slices <= 1024, "adain_split: bad geometry");
-    MNET_CHECK_ARG(dtype == MNET_F32 || dtype == MNET_F16 || dtype == MNET_F16X2, "adain_split: bad dtype");
-    MNET_CHECK_ALIGN(dtype != MNET_F16X2 || (aligned128(prior) && aligned128(feat) && aligned128(out)), "adain_split: split-half tensors must be 128-byte aligned");
+    MNET_CHECK_ARG(dtype == MNET_F32 || dtype == MNET_F16 || is_split4(dtype), "adain_split: bad dtype");
+    MNET_CHECK_ALIGN(!is_split4(dtype) || (aligned128(prior) && aligned128(feat) && aligned128(out)), "adain_split: split-half tensors must be 128-byte aligned");
     MNET_CHECK_ARG((gamma != nullptr) == (beta != nullptr) && (gamma != nullptr) == (scale != nullptr) && (gamma != nullptr) == (shift != nullptr),
                    "adain_split: gamma, beta, scale, shift go together");
     const int N = dtype == MNET_F32 ? 4 : 8;
@@ -568,16 +582,19 @@ extern "C" int mnet_adain_crop_concat_split(const void* prior, const void* feat,
     if (!attr_once.done()) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(adain_stats_kernel<f16>), hipFuncAttributeMaxDynamicSharedMemorySize, 256 * 8 * 4 * 8);
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(adain_stats_kernel<hs>), hipFuncAttributeMaxDynamicSharedMemorySize, 256 * 8 * 4 * 8);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(adain_stats_kernel<hm>), hipFuncAttributeMaxDynamicSharedMemorySize, 256 * 8 * 4 * 8);
         attr_once.mark();
     }
     if (dtype == MNET_F16) hipLaunchKernelGGL(adain_stats_kernel<f16>, dim3(slices, G), dim3(256), lds1, st, (const f16*)prior, (const f16*)feat, S, C, feat_w, g_img, g_x1, g_y1, g_w, partial, slices);
     else if (dtype == MNET_F16X2) hipLaunchKernelGGL(adain_stats_kernel<hs>, dim3(slices, G), dim3(256), lds1, st, (const hs*)prior, (const hs*)feat, S, C, feat_w, g_img, g_x1, g_y1, g_w, partial, slices);
+    else if (dtype == MNET_F16M) hipLaunchKernelGGL(adain_stats_kernel<hm>, dim3(slices, G), dim3(256), lds1, st, (const hm*)prior, (const hm*)feat, S, C, feat_w, g_img, g_x1, g_y1, g_w, partial, slices);
     else hipLaunchKernelGGL(adain_stats_kernel<float>, dim3(slices, G), dim3(256), lds1, st, (const float*)prior, (const float*)feat, S, C, feat_w, g_img, g_x1, g_y1, g_w, partial, slices);
     MNET_LAUNCH_CHECK("adain_stats");
     hipLaunchKernelGGL(adain_finalize_kernel, dim3(G), dim3(256), lds2, st, partial, slices, S, C, g_w, stat, gamma, beta, eps, scale, shift);
     MNET_LAUNCH_CHECK("adain_finalize");
     if (dtype == MNET_F16) hipLaunchKernelGGL(adain_apply_kernel<f16>, dim3(slices, G), dim3(256), lds3, st, (const f16*)prior, (const f16*)feat, (f16*)out, S, C, feat_w, g_img, g_x1, g_y1, g_w, stat, slices);
     else if (dtype == MNET_F16X2) hipLaunchKernelGGL(adain_apply_kernel<hs>, dim3(slices, G), dim3(256), lds3, st, (const hs*)prior, (const hs*)feat, (hs*)out, S, C, feat_w, g_img, g_x1, g_y1, g_w, stat, slices);
+    else if (dtype == MNET_F16M) hipLaunchKernelGGL(adain_apply_kernel<hm>, dim3(slices, G), dim3(256), lds3, st, (const hm*)prior, (const hm*)feat, (hm*)out, S, C, feat_w, g_img, g_x1, g_y1, g_w, stat, slices);
     else hipLaunchKernelGGL(adain_apply_kernel<float>, dim3(slices, G), dim3(256), lds3, st, (const float*)prior, (const float*)feat, (float*)out, S, C, feat_w, g_img, g_x1, g_y1, g_w, stat, slices);
     MNET_LAUNCH_CHECK("adain_apply");
     return MNET_OK;
@@ -631,9 +648,9 @@ extern "C" int mnet_glyph_scatter_affine(const void* feat, const void* scale, co
                                          const int32_t* g_start, const int32_t* g_x1, const int32_t* g_w, void* stream) {
     MNET_CHECK_ARG(feat && scale && shift && out && g_start && g_x1 && g_w, "scatter: null pointer");
     MNET_CHECK_ARG(B > 0 && S > 0 && C > 0 && feat_w > 0, "scatter: bad geometry");
-    MNET_CHECK_ARG(dtype == MNET_F32 || dtype == MNET_F16 || dtype == MNET_F16X2, "scatter: bad dtype");
+    MNET_CHECK_ARG(dtype == MNET_F32 || dtype == MNET_F16 || is_split4(dtype), "scatter: bad dtype");
     const int N = dtype == MNET_F32 ? 4 : 8;
-    MNET_CHECK_ALIGN(dtype != MNET_F16X2 || (C % 32 == 0 && aligned128(feat) && aligned128(scale) && aligned128(shift) && aligned128(out)),
+    MNET_CHECK_ALIGN(!is_split4(dtype) || (C % 32 == 0 && aligned128(feat) && aligned128(scale) && aligned128(shift) && aligned128(out)),
                      "scatter: split-half needs C %% 32 == 0, 128-byte aligned");
     MNET_CHECK_ALIGN(C % N == 0 && aligned16(feat) && aligned16(scale) && aligned16(shift) && aligned16(out),
                      "scatter: unaligned");
@@ -642,6 +659,7 @@ extern "C" int mnet_glyph_scatter_affine(const void* feat, const void* scale, co
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     if (dtype == MNET_F16) hipLaunchKernelGGL(glyph_scatter_kernel<f16>, dim3(blocks, B), dim3(256), 0, st, (const f16*)feat, (const f16*)scale, (const f16*)shift, (f16*)out, S, C, feat_w, g_start, g_x1, g_w);
     else if (dtype == MNET_F16X2) hipLaunchKernelGGL(glyph_scatter_kernel<hs>, dim3(blocks, B), dim3(256), 0, st, (const hs*)feat, (const hs*)scale, (const hs*)shift, (hs*)out, S, C, feat_w, g_start, g_x1, g_w);
+    else if (dtype == MNET_F16M) hipLaunchKernelGGL(glyph_scatter_kernel<hm>, dim3(blocks, B), dim3(256), 0, st, (const hm*)feat, (const hm*)scale, (const hm*)shift, (hm*)out, S, C, feat_w, g_start, g_x1, g_w);
     else hipLaunchKernelGGL(glyph_scatter_kernel<float>, dim3(blocks, B), dim3(256), 0, st, (const float*)feat, (const float*)scale, (const float*)shift, (float*)out, S, C, feat_w, g_start, g_x1, g_w);
     MNET_LAUNCH_CHECK("glyph_scatter");
     return MNET_OK;
@@ -671,15 +689,16 @@ __global__ void __launch_bounds__(256) embed_gather_kernel(const float* __restri
 extern "C" int mnet_embed_gather(const float* emb, const int64_t* labels, void* out, int32_t dtype, int32_t N_,
                                  int32_t nc, int32_t C, int32_t num_classes, void* stream) {
     MNET_CHECK_ARG(emb && labels && out && N_ > 0 && nc > 0 && C > 0 && num_classes > 0, "embed_gather: bad args");
-    MNET_CHECK_ARG(dtype == MNET_F32 || dtype == MNET_F16 || dtype == MNET_F16X2, "embed_gather: bad dtype");
+    MNET_CHECK_ARG(dtype == MNET_F32 || dtype == MNET_F16 || is_split4(dtype), "embed_gather: bad dtype");
     const int N = dtype == MNET_F32 ? 4 : 8;
     MNET_CHECK_ALIGN(C % N == 0 && aligned16(out), "embed_gather: unaligned");
-    MNET_CHECK_ALIGN(dtype != MNET_F16X2 || (C % 32 == 0 && aligned128(out)), "embed_gather: split-half needs C %% 32 == 0, 128-byte aligned");
+    MNET_CHECK_ALIGN(!is_split4(dtype) || (C % 32 == 0 && aligned128(out)), "embed_gather: split-half needs C %% 32 == 0, 128-byte aligned");
     const long long total = (long long)N_ * 16 * nc * (C / N);
     const int blocks = (int)((total + 255) / 256 < 16384 ? (total + 255) / 256 : 16384);
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     if (dtype == MNET_F16) hipLaunchKernelGGL(embed_gather_kernel<f16>, dim3(blocks), dim3(256), 0, st, emb, labels, (f16*)out, nc, C, total);
     else if (dtype == MNET_F16X2) hipLaunchKernelGGL(embed_gather_kernel<hs>, dim3(blocks), dim3(256), 0, st, emb, labels, (hs*)out, nc, C, total);
+    else if (dtype == MNET_F16M) hipLaunchKernelGGL(embed_gather_kernel<hm>, dim3(blocks), dim3(256), 0, st, emb, labels, (hm*)out, nc, C, total);
     else hipLaunchKernelGGL(embed_gather_kernel<float>, dim3(blocks), dim3(256), 0, st, emb, labels, (float*)out, nc, C, total);
     MNET_LAUNCH_CHECK("embed_gather");
     return MNET_OK;
@@ -771,21 +790,23 @@ template <typename S>
 static void convert_from(const void* src, void* dst, int32_t dst_dtype, long long n8, int blocks, hipStream_t st) {
     if (dst_dtype == MNET_F32) hipLaunchKernelGGL((convert_kernel<S, float>), dim3(blocks), dim3(256), 0, st, (const S*)src, (float*)dst, n8);
     else if (dst_dtype == MNET_F16) hipLaunchKernelGGL((convert_kernel<S, f16>), dim3(blocks), dim3(256), 0, st, (const S*)src, (f16*)dst, n8);
+    else if (dst_dtype == MNET_F16M) hipLaunchKernelGGL((convert_kernel<S, hm>), dim3(blocks), dim3(256), 0, st, (const S*)src, (hm*)dst, n8);
     else hipLaunchKernelGGL((convert_kernel<S, hs>), dim3(blocks), dim3(256), 0, st, (const S*)src, (hs*)dst, n8);
 }
 
 extern "C" int mnet_convert(const void* src, int32_t src_dtype, void* dst, int32_t dst_dtype, int64_t count, void* stream) {
     MNET_CHECK_ARG(src && dst && count > 0 && count % 8 == 0, "convert: bad args (count %% 8 == 0)");
-    MNET_CHECK_ARG(src_dtype >= MNET_F32 && src_dtype <= MNET_F16X2 && dst_dtype >= MNET_F32 && dst_dtype <= MNET_F16X2, "convert: bad dtype");
+    MNET_CHECK_ARG(src_dtype >= MNET_F32 && src_dtype <= MNET_F16M && dst_dtype >= MNET_F32 && dst_dtype <= MNET_F16M, "convert: bad dtype");
     MNET_CHECK_ALIGN(aligned16(src) && aligned16(dst), "convert: unaligned pointer");
-    MNET_CHECK_ALIGN((src_dtype != MNET_F16X2 || aligned128(src)) && (dst_dtype != MNET_F16X2 || aligned128(dst)) &&
-                     ((src_dtype != MNET_F16X2 && dst_dtype != MNET_F16X2) || count % 32 == 0),
+    MNET_CHECK_ALIGN((!is_split4(src_dtype) || aligned128(src)) && (!is_split4(dst_dtype) || aligned128(dst)) &&
+                     ((!is_split4(src_dtype) && !is_split4(dst_dtype)) || count % 32 == 0),
                      "convert: split-half tensors need count %% 32 == 0 and a 128-byte aligned base");
     const long long n8 = count / 8;
     const int blocks = (int)((n8 + 255) / 256 < 16384 ? (n8 + 255) / 256 : 16384);
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     if (src_dtype == MNET_F32) convert_from<float>(src, dst, dst_dtype, n8, blocks, st);
     else if (src_dtype == MNET_F16) convert_from<f16>(src, dst, dst_dtype, n8, blocks, st);
+    else if (src_dtype == MNET_F16M) convert_from<hm>(src, dst, dst_dtype, n8, blocks, st);
     else convert_from<hs>(src, dst, dst_dtype, n8, blocks, st);
     MNET_LAUNCH_CHECK("convert");
     return MNET_OK;
@@ -857,9 +878,9 @@ __global__ void __launch_bounds__(256) affine_act_kernel(const T* __restrict__ x
 extern "C" int mnet_affine_act_nhwc(const void* x, void* y, int32_t dtype, int32_t n, int32_t hw, int32_t c,
                                     const float* scale, const float* shift, int32_t swish, void* stream) {
     MNET_CHECK_ARG(x && y && scale && n > 0 && hw > 0 && c > 0 && n <= 65535, "affine_act: bad args");
-    MNET_CHECK_ARG(dtype == MNET_F32 || dtype == MNET_F16 || dtype == MNET_F16X2, "affine_act: bad dtype");
+    MNET_CHECK_ARG(dtype == MNET_F32 || dtype == MNET_F16 || is_split4(dtype), "affine_act: bad dtype");
     const int N = dtype == MNET_F32 ? 4 : 8;
-    MNET_CHECK_ALIGN(dtype != MNET_F16X2 || (c % 32 == 0 && aligned128(x) && aligned128(y)), "affine_act: split-half needs c %% 32 == 0, 128-byte aligned");
+    MNET_CHECK_ALIGN(!is_split4(dtype) || (c % 32 == 0 && aligned128(x) && aligned128(y)), "affine_act: split-half needs c %% 32 == 0, 128-byte aligned");
     MNET_CHECK_ALIGN(c % N == 0 && 256 % (c / N) == 0 && aligned16(x) && aligned16(y) && aligned16(scale) && aligned16(shift),
                      "affine_act: c=%d unsupported or unaligned", c);
     const long long per = (long long)hw * (c / N);
@@ -868,6 +889,7 @@ extern "C" int mnet_affine_act_nhwc(const void* x, void* y, int32_t dtype, int32
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     if (dtype == MNET_F16) hipLaunchKernelGGL(affine_act_kernel<f16>, dim3(gx, n), dim3(256), 0, st, (const f16*)x, (f16*)y, c, scale, shift, swish, (unsigned)per);
     else if (dtype == MNET_F16X2) hipLaunchKernelGGL(affine_act_kernel<hs>, dim3(gx, n), dim3(256), 0, st, (const hs*)x, (hs*)y, c, scale, shift, swish, (unsigned)per);
+    else if (dtype == MNET_F16M) hipLaunchKernelGGL(affine_act_kernel<hm>, dim3(gx, n), dim3(256), 0, st, (const hm*)x, (hm*)y, c, scale, shift, swish, (unsigned)per);
     else hipLaunchKernelGGL(affine_act_kernel<float>, dim3(gx, n), dim3(256), 0, st, (const float*)x, (float*)y, c, scale, shift, swish, (unsigned)per);
     MNET_LAUNCH_CHECK("affine_act");
     return MNET_OK;
@@ -921,7 +943,7 @@ template <> struct RgbW<float> { typedef float pair_t; };
 
 // SPLIT (T = float): the input is a split-half tensor, converted to fp32 while it is staged; weights, arithmetic and both
 // outputs are the fp32 ones.
-template <typename T, int CIN, bool SPLIT = false>
+template <typename T, int CIN, bool SPLIT = false, typename ST = hs>
 __global__ void __launch_bounds__(256) conv3x3_rgb_kernel(const T* __restrict__ x, const void* __restrict__ wgt_,
                                                           const float* __restrict__ bias, T* __restrict__ y_nhwc,
                                                           float* __restrict__ y_nchw, int H, int W, int act) {
@@ -942,7 +964,7 @@ __global__ void __launch_bounds__(256) conv3x3_rgb_kernel(const T* __restrict__ 
     if constexpr (SPLIT) {
         // split-half input: converted to fp32 while staged, 32 channels (one split block) at a time — a 43.5 KiB patch instead of
         // 87 KiB, so three workgroups share a CU instead of one (the kernel is a chain of LDS / global latencies at 4 waves per CU)
-        const hs* xs = reinterpret_cast<const hs*>(x) + (size_t)n * H * W * CIN;
+        const ST* xs = reinterpret_cast<const ST*>(x) + (size_t)n * H * W * CIN;
         const float* wp = reinterpret_cast<const float*>(wgt_);              // [3][9][CIN]
         auto off32 = [](int q, int c) __attribute__((always_inline)) { return q * 128 + ((c ^ ((q >> 1) & 7)) << 4); };   // 128-byte rows, 8 chunks
         const int ly_ = t / TW, lx_ = t - ly_ * TW;
@@ -954,7 +976,7 @@ __global__ void __launch_bounds__(256) conv3x3_rgb_kernel(const T* __restrict__ 
                 const int py = q / PW, px = q - py * PW;
                 const int gy = y0 + py, gx = x0 + px;
                 float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-                if ((unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W) unpackr<hs>(ldraw<hs>(xs + ((size_t)gy * W + gx) * CIN + half * 32 + c8 * 8), v);
+                if ((unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W) unpackr<ST>(ldraw<ST>(xs + ((size_t)gy * W + gx) * CIN + half * 32 + c8 * 8), v);
                 *reinterpret_cast<u32x4*>(dyn + off32(q, 2 * c8)) = Vec<float>::pack(v);
                 *reinterpret_cast<u32x4*>(dyn + off32(q, 2 * c8 + 1)) = Vec<float>::pack(v + 4);
             }
@@ -976,7 +998,9 @@ __global__ void __launch_bounds__(256) conv3x3_rgb_kernel(const T* __restrict__ 
         const int oy_ = ty * TH + ly_, ox_ = tx * TW + lx_;
         if (oy_ >= H || ox_ >= W) return;
         float r[8] = {b0 + bias[0], b1 + bias[1], b2 + bias[2], 0.f, 0.f, 0.f, 0.f, 0.f};
-        if (act == MNET_ACT_TANH) { r[0] = tanhf(r[0]); r[1] = tanhf(r[1]); r[2] = tanhf(r[2]); }
+        // half-range storage: an overflowed (infinite) pre-activation must not hide behind tanh's saturation — it is written as NaN
+        // (tanhf(inf - inf) is NaN already), so that the pipeline's finiteness check of the SR result sees it
+        if (act == MNET_ACT_TANH) { r[0] = tanhf(r[0] - r[0] + r[0]); r[1] = tanhf(r[1] - r[1] + r[1]); r[2] = tanhf(r[2] - r[2] + r[2]); }
         if (y_nhwc) {
             T* yp = y_nhwc + (((size_t)n * H + oy_) * W + ox_) * 8;
             stg16(yp, Vec<float>::pack(r)); stg16(yp + 4, Vec<float>::pack(r + 4));
@@ -1038,7 +1062,11 @@ __global__ void __launch_bounds__(256) conv3x3_rgb_kernel(const T* __restrict__ 
     }
     if (oy >= H || ox >= W) return;
     float r[8] = {a0 + bias[0], a1 + bias[1], a2 + bias[2], 0.f, 0.f, 0.f, 0.f, 0.f};
-    if (act == MNET_ACT_TANH) { r[0] = tanhf(r[0]); r[1] = tanhf(r[1]); r[2] = tanhf(r[2]); }
+    if (act == MNET_ACT_TANH) {
+        if constexpr (sizeof(T) == 2) {      // f16 storage: see above (an infinite pre-activation becomes NaN, not +-1)
+            r[0] = tanhf(r[0] - r[0] + r[0]); r[1] = tanhf(r[1] - r[1] + r[1]); r[2] = tanhf(r[2] - r[2] + r[2]);
+        } else { r[0] = tanhf(r[0]); r[1] = tanhf(r[1]); r[2] = tanhf(r[2]); }
+    }
     if (y_nhwc) {
         T* yp = y_nhwc + (((size_t)n * H + oy) * W + ox) * 8;
         if constexpr (sizeof(T) == 2) stg16(yp, Vec<f16>::pack(r));
@@ -1056,9 +1084,9 @@ __global__ void __launch_bounds__(256) conv3x3_rgb_kernel(const T* __restrict__ 
 extern "C" int mnet_conv3x3_rgb(const void* x, int32_t dtype, int32_t n, int32_t h, int32_t w, int32_t cin, const void* wgt,
                                 const float* bias, int32_t act, void* y_nhwc, float* y_nchw, void* stream) {
     MNET_CHECK_ARG(x && wgt && bias && (y_nhwc || y_nchw) && n > 0 && h > 0 && w > 0 && n <= 65535, "conv3x3_rgb: bad args");
-    MNET_CHECK_ARG(dtype == MNET_F32 || dtype == MNET_F16 || dtype == MNET_F16X2, "conv3x3_rgb: bad dtype");
+    MNET_CHECK_ARG(dtype == MNET_F32 || dtype == MNET_F16 || is_split4(dtype), "conv3x3_rgb: bad dtype");
     MNET_CHECK_ARG(cin == 64, "conv3x3_rgb: cin=%d (supported: 64)", cin);
-    MNET_CHECK_ALIGN(dtype != MNET_F16X2 || aligned128(x), "conv3x3_rgb: split-half input must be 128-byte aligned");
+    MNET_CHECK_ALIGN(!is_split4(dtype) || aligned128(x), "conv3x3_rgb: split-half input must be 128-byte aligned");
     MNET_CHECK_ARG(act == MNET_ACT_NONE || act == MNET_ACT_TANH, "conv3x3_rgb: act %d", act);
     MNET_CHECK_ALIGN(aligned16(x) && aligned16(y_nhwc) && aligned16(wgt), "conv3x3_rgb: unaligned pointer");
     const int tiles = ((h + 7) / 8) * ((w + 31) / 32);
@@ -1072,10 +1100,12 @@ extern "C" int mnet_conv3x3_rgb(const void* x, int32_t dtype, int32_t n, int32_t
         if (!attr_once.done()) {
             hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_rgb_kernel<float, 64>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
             if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_rgb_kernel<float, 64, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+            if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_rgb_kernel<float, 64, true, hm>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
             if (e != hipSuccess) return mnet_fail(MNET_E_LAUNCH, "hipFuncSetAttribute(conv3x3_rgb): %s", hipGetErrorString(e));
             attr_once.mark();
         }
         if (dtype == MNET_F16X2) hipLaunchKernelGGL((conv3x3_rgb_kernel<float, 64, true>), dim3(tiles, n), dim3(256), 10 * 34 * 32 * 4, st, (const float*)x, wgt, bias, (float*)y_nhwc, y_nchw, h, w, act);
+        else if (dtype == MNET_F16M) hipLaunchKernelGGL((conv3x3_rgb_kernel<float, 64, true, hm>), dim3(tiles, n), dim3(256), 10 * 34 * 32 * 4, st, (const float*)x, wgt, bias, (float*)y_nhwc, y_nchw, h, w, act);
         else hipLaunchKernelGGL((conv3x3_rgb_kernel<float, 64>), dim3(tiles, n), dim3(256), lds, st, (const float*)x, wgt, bias, (float*)y_nhwc, y_nchw, h, w, act);
     }
     MNET_LAUNCH_CHECK("conv3x3_rgb");

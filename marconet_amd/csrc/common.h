@@ -137,6 +137,112 @@ template <> __device__ __forceinline__ void st_elem<hs>(hs* px, int c, float v) 
     q[0] = h; q[32] = (f16)(v - (float)h);
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// MNET_F16M — "fp16+8" storage of the fp16x2 precision mode (layout: include/marconet_hip.h).  Same nominal addressing as hs
+// (chunk j of a pixel at +32 j bytes).  A chunk of 8 channels = 8 hi halves + 8 lo bytes + the E8M0 exponent of ITS BLOCK's scale,
+// which is shared by the 4 chunks of the block: packr<hm> therefore reduces over the 4 lanes of a quad — every kernel that stores
+// hm chunks keeps chunk j of a pixel in lane j (mod 4) of a fully active quad (linear thread -> chunk maps, C % 32 == 0).
+struct hm { unsigned int bits; };
+static_assert(sizeof(hm) == 4, "hm is 4 bytes");
+template <> struct Vec<hm> { static constexpr int N = 8; };
+template <> struct Raw<hm> { u32x4 hi; u32x2 lo8; int e8; };
+
+// 8-byte slot of the lo bytes of chunk s (channels 8 s .. 8 s + 7) inside the block's 32 lo bytes (order 0-7,16-23,8-15,24-31)
+__device__ __forceinline__ int hm_lo_slot(int s) { return ((s & 1) << 1) | (s >> 1); }
+
+template <> __device__ __forceinline__ Raw<hm> ldraw<hm>(const hm* p) {
+    const uintptr_t a = reinterpret_cast<uintptr_t>(p);
+    const unsigned s = (unsigned)(a >> 5) & 3u;
+    const unsigned char* blk = reinterpret_cast<const unsigned char*>(a - s * 32u);
+    Raw<hm> r;
+    r.hi = ldg16(blk + s * 16u);
+    r.lo8 = *reinterpret_cast<const u32x2*>(blk + 64 + hm_lo_slot((int)s) * 8);
+    r.e8 = blk[96];
+    return r;
+}
+template <> __device__ __forceinline__ void straw<hm>(hm* p, const Raw<hm>& r) {
+    const uintptr_t a = reinterpret_cast<uintptr_t>(p);
+    const unsigned s = (unsigned)(a >> 5) & 3u;
+    unsigned char* blk = reinterpret_cast<unsigned char*>(a - s * 32u);
+    stg16(blk + s * 16u, r.hi);
+    *reinterpret_cast<u32x2*>(blk + 64 + hm_lo_slot((int)s) * 8) = r.lo8;
+    if (s == 0) stg16(blk + 96, u32x4{(unsigned)r.e8, 0u, 0u, 0u});       // the whole 128-byte line is written: no partial-line
+    if (s == 1) stg16(blk + 112, u32x4{0u, 0u, 0u, 0u});                  // write-back, deterministic padding
+}
+template <> __device__ __forceinline__ Raw<hm> zero_raw<hm>() { Raw<hm> r; r.hi = u32x4{0u, 0u, 0u, 0u}; r.lo8 = u32x2{0u, 0u}; r.e8 = 0; return r; }
+
+// lo scale 2^(E - 127 - 11) as a float (0 for blocks too small to matter)
+__device__ __forceinline__ float hm_lo_scale(int e8) { return e8 >= 12 ? __builtin_bit_cast(float, (unsigned)(e8 - 11) << 23) : 0.f; }
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void hm_decode_lo(u32x2 lo8, float sl, float* o) {
+#pragma unroll
+    for (int d = 0; d < 2; ++d) {
+        const f32x2 a = __builtin_amdgcn_cvt_pk_f32_fp8((int)lo8[d], false), b = __builtin_amdgcn_cvt_pk_f32_fp8((int)lo8[d], true);
+        o[4 * d] = a[0] * sl; o[4 * d + 1] = a[1] * sl; o[4 * d + 2] = b[0] * sl; o[4 * d + 3] = b[1] * sl;
+    }
+}
+template <> __device__ __forceinline__ void unpackr<hm>(const Raw<hm>& r, float* o) {
+    const f16x8 h = bitcast<f16x8>(r.hi);
+    float l[8];
+    hm_decode_lo(r.lo8, hm_lo_scale(r.e8), l);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) o[j] = (float)h[j] + l[j];
+}
+// E8M0 byte of the block scale from the block's max |hi| (as a float): 2^(floor(log2 m) - 7)
+__device__ __forceinline__ int hm_e8_of(float m) { return max(0, (int)((__builtin_bit_cast(unsigned, m) >> 23) & 255u) - 7); }
+// 8 lo bytes: e4m3((v - hi) * 2^11 / s), s = 2^(e8 - 127)
+__device__ __forceinline__ u32x2 hm_encode_lo(const float* o, const f16x8& h, int e8) {
+    const float inv = e8 >= 11 ? __builtin_bit_cast(float, (unsigned)(265 - e8) << 23) : 0.f;      // 2^(11 + 127 - e8)
+    u32x2 r;
+#pragma unroll
+    for (int d = 0; d < 2; ++d) {
+        int w = 0;
+        w = __builtin_amdgcn_cvt_pk_fp8_f32((o[4 * d] - (float)h[4 * d]) * inv, (o[4 * d + 1] - (float)h[4 * d + 1]) * inv, w, false);
+        w = __builtin_amdgcn_cvt_pk_fp8_f32((o[4 * d + 2] - (float)h[4 * d + 2]) * inv, (o[4 * d + 3] - (float)h[4 * d + 3]) * inv, w, true);
+        r[d] = (unsigned)w;
+    }
+    return r;
+}
+__device__ __forceinline__ float quad_max(float m) {      // max over the 4 lanes of a quad (DPP quad_perm: xor 1, xor 2)
+    m = fmaxf(m, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, m), 0xB1, 0xf, 0xf, true)));
+    m = fmaxf(m, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, m), 0x4E, 0xf, 0xf, true)));
+    return m;
+}
+template <> __device__ __forceinline__ Raw<hm> packr<hm>(const float* o) {
+    Raw<hm> r;
+    f16x8 h;
+    float m = 0.f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { h[j] = (f16)o[j]; m = fmaxf(m, fabsf((float)h[j])); }
+    r.e8 = hm_e8_of(quad_max(m));
+    r.hi = bitcast<u32x4>(h);
+    r.lo8 = hm_encode_lo(o, h, r.e8);
+    return r;
+}
+template <> __device__ __forceinline__ float ld_elem<hm>(const hm* px, int c) {
+    const unsigned char* blk = reinterpret_cast<const unsigned char*>(px) + (c >> 5) * 128;
+    const int ci = c & 31;
+    const float hi = (float)reinterpret_cast<const f16*>(blk)[ci];
+    const int b = blk[64 + hm_lo_slot(ci >> 3) * 8 + (ci & 7)];
+    const f32x2 lo = __builtin_amdgcn_cvt_pk_f32_fp8(b, false);
+    return hi + lo[0] * hm_lo_scale(blk[96]);
+}
+// one lane per channel, the 32 channels of a block in 32 consecutive lanes (lane % 32 == c % 32), all active
+__device__ __forceinline__ void st_block32_hm(hm* px, int c, float v) {
+    unsigned char* blk = reinterpret_cast<unsigned char*>(px) + (c >> 5) * 128;
+    const int ci = c & 31;
+    const f16 h = (f16)v;
+    float m = fabsf((float)h);
+#pragma unroll
+    for (int o = 16; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+    const int e8 = hm_e8_of(m);
+    const float inv = e8 >= 11 ? __builtin_bit_cast(float, (unsigned)(265 - e8) << 23) : 0.f;
+    reinterpret_cast<f16*>(blk)[ci] = h;
+    blk[64 + hm_lo_slot(ci >> 3) * 8 + (ci & 7)] = (unsigned char)(__builtin_amdgcn_cvt_pk_fp8_f32((v - (float)h) * inv, 0.f, 0, false) & 0xff);
+    if (ci == 0) blk[96] = (unsigned char)e8;
+    if (ci >= 1) blk[96 + ci] = 0;
+}
+
 static inline bool aligned128(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 127u) == 0; }
 
 __device__ __forceinline__ float act_apply(float v, int act) {

@@ -47,6 +47,82 @@ __device__ __forceinline__ int dma_weight_channel(int row) {
     }
 }
 
+// fp16+8 (MNET_F16M) launches, MF = 32: LDS row 64b + 32f + i (fragment parity f, D row i = 8q + 4h + e of lane-half h) holds
+// channel 64b + 32h + 16f + 4q + e — the 2 x 16 accumulator values of a lane for one pixel (fragments 2b, 2b+1) are then the 32
+// CONSECUTIVE channels of one storage block: its scale exponent needs no cross-lane step and the block is stored as 128 contiguous
+// bytes by one lane
+__device__ __forceinline__ int dma_weight_channel_mx(int row) {
+    const int f = (row >> 5) & 1, i = row & 31;
+    return (row & ~63) + (((i >> 2) & 1) << 5) + (f << 4) + ((i >> 3) << 2) + (i & 3);
+}
+
+// Epilogue of an fp16+8 tile (same passes, same order of operations as dma_epilogue): every lane owns, per pixel, FC/4 whole
+// 32-channel blocks.
+template <int BC, int BP, int WC, int WP, int FC, int FP>
+__device__ __forceinline__ void dma_epilogue_mx(const ConvArgs& p, const f32x16 (&acc32)[FC / 2][FP / 2], int co0, int pix0, int wc, int wp, int lane) {
+    constexpr int NPX = FP / 2, NB = FC / 4;
+    const int h = lane >> 5;
+    const int last_pix = p.npix - 1;
+#pragma unroll
+    for (int px = 0; px < NPX; ++px) {
+        const int pix = pix0 + wp * (BP / WP) + px * 32 + (lane & 31);
+        const int n_img = min(pix, last_pix) / p.howo;
+#pragma unroll
+        for (int b = 0; b < NB; ++b) {
+            const int co = co0 + wc * (BC / WC) + b * 64 + h * 32;         // first channel of this lane's block
+            float v[32];
+#pragma unroll
+            for (int q = 0; q < 16; ++q) { v[q] = acc32[2 * b][px][q] * MNET_SPLIT_WSCALE_INV; v[16 + q] = acc32[2 * b + 1][px][q] * MNET_SPLIT_WSCALE_INV; }
+            if (co >= p.cout) continue;
+            if (p.out_scale) {
+                const float* sp = p.out_scale + (size_t)n_img * p.cout + co;
+#pragma unroll
+                for (int q = 0; q < 32; q += 4) { const f32x4 s4 = *reinterpret_cast<const f32x4*>(sp + q); v[q] *= s4[0]; v[q + 1] *= s4[1]; v[q + 2] *= s4[2]; v[q + 3] *= s4[3]; }
+            }
+            if (p.bias) {
+#pragma unroll
+                for (int q = 0; q < 32; q += 4) { const f32x4 b4 = *reinterpret_cast<const f32x4*>(p.bias + co + q); v[q] += b4[0]; v[q + 1] += b4[1]; v[q + 2] += b4[2]; v[q + 3] += b4[3]; }
+            }
+            if (p.res && pix < p.npix) {
+                const int rpix = p.res_mod > 0 ? pix % p.res_mod : pix;
+                const unsigned char* rb = reinterpret_cast<const unsigned char*>(p.res) + (size_t)rpix * p.cout * 4 + (co >> 5) * 128;
+                const float sl = hm_lo_scale(rb[96]);
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    const f16x8 h8 = bitcast<f16x8>(ldg16(rb + c * 16));
+                    float l[8];
+                    hm_decode_lo(*reinterpret_cast<const u32x2*>(rb + 64 + hm_lo_slot(c) * 8), sl, l);
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) v[c * 8 + q] += (float)h8[q] + l[q];
+                }
+            }
+            act_apply_vec<32, true>(v, p.act);
+            if (p.post_scale) {
+                const float* sp = p.post_scale + (size_t)n_img * p.cout + co;
+#pragma unroll
+                for (int q = 0; q < 32; q += 4) { const f32x4 s4 = *reinterpret_cast<const f32x4*>(sp + q); v[q] *= s4[0]; v[q + 1] *= s4[1]; v[q + 2] *= s4[2]; v[q + 3] *= s4[3]; }
+            }
+            if (pix >= p.npix) continue;
+            unsigned char* yb = reinterpret_cast<unsigned char*>(p.y) + (size_t)pix * p.cout * 4 + (co >> 5) * 128;
+            f16x8 hh[4];
+            float m = 0.f;
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+#pragma unroll
+                for (int q = 0; q < 8; ++q) { hh[c][q] = (f16)v[c * 8 + q]; m = fmaxf(m, fabsf((float)hh[c][q])); }
+            const int e8 = hm_e8_of(m);
+            u32x2 lo[4];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) { stg16(yb + c * 16, bitcast<u32x4>(hh[c])); lo[c] = hm_encode_lo(v + c * 8, hh[c], e8); }
+            // lo bytes in the order 0-7,16-23 | 8-15,24-31 (slot of chunk c = hm_lo_slot(c))
+            stg16(yb + 64, u32x4{lo[0][0], lo[0][1], lo[2][0], lo[2][1]});
+            stg16(yb + 80, u32x4{lo[1][0], lo[1][1], lo[3][0], lo[3][1]});
+            stg16(yb + 96, u32x4{(unsigned)e8, 0u, 0u, 0u});
+            stg16(yb + 112, u32x4{0u, 0u, 0u, 0u});
+        }
+    }
+}
+
 // Epilogue of one (cout tile co0, pixel tile pix0): identical math to conv_igemm.hip.  Every lane owns NG groups of 8
 // consecutive output channels for each of its NPX pixels; whole-register-set passes, each behind ONE wave-uniform branch
 // (out_scale / bias / residual / activation / post_scale), then 16-byte stores.

@@ -51,6 +51,26 @@ __device__ __forceinline__ int swz(int row, int chunk) { return row * 128 + ((ch
 // the same 32 channels — and the host passes c0 / c1 / cin / K in physical (doubled) units.
 template <typename T> struct Phys { typedef T type; };
 template <> struct Phys<hs> { typedef f16 type; };
+template <> struct Phys<hm> { typedef f16 type; };      // fp16+8: staged into LDS as a split-half slab (the lo bytes decoded to halves)
+
+// fp16+8 operands of the register-staged kernel: chunk cc (0-3: hi halves, 4-7: the lo part of channels 8 (cc-4) ..) of the
+// 128-byte block at `blk`, in split-half form — the lo bytes become halves (lo8 * s * 2^-11 is exact in f16 unless it underflows),
+// and the k-loop then runs the three-product split-half MFMA sequence unchanged.
+__device__ __forceinline__ u32x4 hm_lo_halves(u32x2 lo8, float sl) {
+    float l[8];
+    hm_decode_lo(lo8, sl, l);
+    return Vec<f16>::pack(l);
+}
+__device__ __forceinline__ u32x4 ld_hm_act_chunk(const unsigned char* blk, int cc) {
+    if (cc < 4) return ldg16(blk + cc * 16);
+    return hm_lo_halves(*reinterpret_cast<const u32x2*>(blk + 64 + hm_lo_slot(cc - 4) * 8), hm_lo_scale(blk[96]));
+}
+__device__ __forceinline__ u32x4 ld_hm_wgt_chunk(const unsigned char* blk, int cc, int wexp) {      // wexp: E8M0 of s_w * 2^-11
+    if (cc < 4) return ldg16(blk + cc * 16);
+    const int s = cc - 4;
+    return hm_lo_halves(*reinterpret_cast<const u32x2*>(blk + 64 + (s & 1) * 32 + (s >> 1) * 8),
+                        wexp > 0 ? __builtin_bit_cast(float, (unsigned)wexp << 23) : 0.f);
+}
 
 template <typename T>
 __device__ __forceinline__ u32x4 in_transform(u32x4 raw, const float* sc, const float* sh, bool swish) {
@@ -101,6 +121,7 @@ template <typename T, int BC, int BP, int WC, int WP>
 __global__ void __launch_bounds__(256, 2) conv_igemm_kernel(const ConvArgs p) {
     typedef typename Phys<T>::type PT;            // element type the k-loop addresses (f16 for split-half)
     constexpr bool SPLIT = sizeof(T) != sizeof(PT);
+    constexpr bool MXS = __is_same(T, hm);         // fp16+8 storage on both sides of a split-half k-loop
     constexpr int KCH = 16 / (int)sizeof(PT);     // elements per 16-byte chunk
     constexpr int BK = 8 * KCH;                   // elements per 128-byte k-slab
     constexpr int FC = BC / WC / 16, FP = BP / WP / 16;
@@ -156,6 +177,10 @@ __global__ void __launch_bounds__(256, 2) conv_igemm_kernel(const ConvArgs p) {
         for (int i = 0; i < WROWS; ++i) {
             const int row = r0 + 32 * i, co = co0 + row;
             const bool ok = kok && row < BC && co < p.cout;
+            if constexpr (MXS) {
+                const unsigned char* wb = reinterpret_cast<const unsigned char*>(p.wgt);
+                wreg[i] = ok ? ld_hm_wgt_chunk(wb + ((size_t)co * p.K + (k & ~63)) * 2, cc, wb[(size_t)p.cout * p.K * 2 + co]) : zero4;
+            } else
             wreg[i] = ok ? ldg16(reinterpret_cast<const PT*>(p.wgt) + (size_t)co * p.K + k) : zero4;
         }
         // activations (implicit im2col gather; channel concat of two sources)
@@ -167,9 +192,15 @@ __global__ void __launch_bounds__(256, 2) conv_igemm_kernel(const ConvArgs p) {
         for (int i = 0; i < XROWS; ++i) {
             const int ih = xih[i] + fr, iw = xiw[i] + fs;
             const bool ok = kok && xn[i] >= 0 && (unsigned)ih < (unsigned)p.h && (unsigned)iw < (unsigned)xvw[i];
+            if constexpr (MXS) {
+                const unsigned char* blk = reinterpret_cast<const unsigned char*>(src + ((size_t)(xn[i] * p.h + ih) * p.w + iw) * cs + (cl & ~63));
+                xreg[i] = ok ? ld_hm_act_chunk(blk, cc) : zero4;
+                if (p.in_scale) xreg2[i] = ok ? ld_hm_act_chunk(blk, cc ^ 4) : zero4;
+            } else {
             xreg[i] = ok ? ldg16(src + ((size_t)(xn[i] * p.h + ih) * p.w + iw) * cs + cl) : zero4;
             if constexpr (SPLIT) {
                 if (p.in_scale) xreg2[i] = ok ? ldg16(src + ((size_t)(xn[i] * p.h + ih) * p.w + iw) * cs + (cl ^ 32)) : zero4;
+            }
             }
             xok |= (ok ? 1u : 0u) << i;
         }
@@ -312,7 +343,15 @@ __global__ void __launch_bounds__(256, 2) conv_igemm_kernel(const ConvArgs p) {
             for (int fa = 0; fa < FC; ++fa) {
                 if (eco[fa] >= p.cout) continue;
                 const T* rp = rs + (size_t)rpix * p.cout + eco[fa];
-                if constexpr (SPLIT) {
+                if constexpr (MXS) {
+                    const unsigned char* rb = reinterpret_cast<const unsigned char*>(rs + (size_t)rpix * p.cout) + (eco[fa] >> 5) * 128;
+                    const int ci = eco[fa] & 31;
+                    const f16x4 h4 = *reinterpret_cast<const f16x4*>(rb + ci * 2);
+                    const int b4 = *reinterpret_cast<const int*>(rb + 64 + hm_lo_slot(ci >> 3) * 8 + (ci & 7));
+                    const float sl = hm_lo_scale(rb[96]);
+                    const f32x2 la = __builtin_amdgcn_cvt_pk_f32_fp8(b4, false), lb = __builtin_amdgcn_cvt_pk_f32_fp8(b4, true);
+                    acc[fa][fb] += f32x4{(float)h4[0] + la[0] * sl, (float)h4[1] + la[1] * sl, (float)h4[2] + lb[0] * sl, (float)h4[3] + lb[1] * sl};
+                } else if constexpr (SPLIT) {
                     const f16* q = reinterpret_cast<const f16*>(rs + (size_t)rpix * p.cout) + (eco[fa] >> 5) * 64 + (eco[fa] & 31);
                     const f16x4 h4 = *reinterpret_cast<const f16x4*>(q), l4 = *reinterpret_cast<const f16x4*>(q + 32);
                     acc[fa][fb] += f32x4{(float)h4[0] + (float)l4[0], (float)h4[1] + (float)l4[1], (float)h4[2] + (float)l4[2], (float)h4[3] + (float)l4[3]};
@@ -349,6 +388,43 @@ __global__ void __launch_bounds__(256, 2) conv_igemm_kernel(const ConvArgs p) {
             for (int fa = 0; fa < FC; ++fa)
                 if (eco[fa] < p.cout) acc[fa][fb] *= *reinterpret_cast<const f32x4*>(sp + eco[fa]);
         }
+    }
+    if constexpr (MXS) {
+        // fp16+8 store: a 32-channel block of one pixel is held by the lanes l16 + 16 g (g = 0..3: 4 channels each) in the fragment
+        // pair (2b, 2b+1): block max over the lane's 8 values, then over g (lanes ^16, ^32); FC is even for every tile that takes a
+        // split launch (cout % 32 == 0, wave tiles of >= 32 channels)
+        if constexpr (FC % 2 == 0)          // (the 16-channel tile never takes a split launch: cout % 32 == 0)
+#pragma unroll
+        for (int fb = 0; fb < FP; ++fb)
+#pragma unroll
+            for (int b = 0; b < FC / 2; ++b) {
+                const f32x4 v0 = acc[2 * b][fb], v1 = acc[2 * b + 1][fb];
+                f16x4 h0, h1;
+                float m = 0.f;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) { h0[q] = (f16)v0[q]; h1[q] = (f16)v1[q]; m = fmaxf(m, fmaxf(fabsf((float)h0[q]), fabsf((float)h1[q]))); }
+                m = fmaxf(m, __shfl_xor(m, 16, 64));
+                m = fmaxf(m, __shfl_xor(m, 32, 64));
+                const int e8 = hm_e8_of(m);
+                const float inv = e8 >= 11 ? __builtin_bit_cast(float, (unsigned)(265 - e8) << 23) : 0.f;
+                if (epix[fb] >= p.npix || eco[2 * b] >= p.cout) continue;
+                unsigned char* yb = reinterpret_cast<unsigned char*>(yo + (size_t)epix[fb] * p.cout) + (eco[2 * b] >> 5) * 128;
+#pragma unroll
+                for (int f = 0; f < 2; ++f) {
+                    const f32x4 v = f ? v1 : v0;
+                    const f16x4 h4 = f ? h1 : h0;
+                    const int ci = eco[2 * b + f] & 31;
+                    *reinterpret_cast<f16x4*>(yb + ci * 2) = h4;
+                    int w = 0;
+                    w = __builtin_amdgcn_cvt_pk_fp8_f32((v[0] - (float)h4[0]) * inv, (v[1] - (float)h4[1]) * inv, w, false);
+                    w = __builtin_amdgcn_cvt_pk_fp8_f32((v[2] - (float)h4[2]) * inv, (v[3] - (float)h4[3]) * inv, w, true);
+                    *reinterpret_cast<int*>(yb + 64 + hm_lo_slot(ci >> 3) * 8 + (ci & 7)) = w;
+                }
+                if (g == 0) *reinterpret_cast<int*>(yb + 96) = e8;
+                if (g == 1) { *reinterpret_cast<int*>(yb + 100) = 0; *reinterpret_cast<u32x2*>(yb + 104) = u32x2{0u, 0u}; }
+                if (g == 2) stg16(yb + 112, u32x4{0u, 0u, 0u, 0u});
+            }
+        return;
     }
 #pragma unroll
     for (int fb = 0; fb < FP; ++fb) {
@@ -427,7 +503,7 @@ static int conv_prepare(const mnet_conv_desc* d, int32_t algo, ConvArgs& a) {
                    (algo >= MNET_CONV_ALGO_STRIP_CFG0 && algo < MNET_CONV_ALGO_STRIP_CFG0 + 3) ||
                    (algo >= MNET_CONV_ALGO_DMA_CFG16 && algo < MNET_CONV_ALGO_DMA_CFG16 + 16), "conv: bad algo %d", algo);
     MNET_CHECK_ARG(d != nullptr, "conv: null descriptor");
-    MNET_CHECK_ARG(d->dtype == MNET_F32 || d->dtype == MNET_F16 || d->dtype == MNET_F16X2, "conv: bad dtype %d", d->dtype);
+    MNET_CHECK_ARG(d->dtype == MNET_F32 || d->dtype == MNET_F16 || d->dtype == MNET_F16X2 || d->dtype == MNET_F16M, "conv: bad dtype %d", d->dtype);
     MNET_CHECK_ARG(d->x0 && d->wgt && d->y, "conv: null tensor pointer");
     MNET_CHECK_ARG(d->n > 0 && d->h > 0 && d->w > 0 && d->ho > 0 && d->wo > 0, "conv: bad geometry");
     MNET_CHECK_ARG(d->c0 > 0 && d->c1 >= 0 && d->cout > 0, "conv: bad channel counts");
@@ -448,7 +524,7 @@ static int conv_prepare(const mnet_conv_desc* d, int32_t algo, ConvArgs& a) {
                      aligned16(d->out_scale) && aligned16(d->bias) && aligned16(d->post_scale), "conv: pointers must be 16-byte aligned");
     const long long npix = (long long)d->n * d->ho * d->wo;
     MNET_CHECK_ARG(npix < (1ll << 31) && (long long)d->n * d->h * d->w < (1ll << 31), "conv: too many pixels");
-    const bool split = d->dtype == MNET_F16X2;
+    const bool split = d->dtype == MNET_F16X2 || d->dtype == MNET_F16M;
     if (split) {
         MNET_CHECK_ALIGN(d->c0 % 32 == 0 && d->c1 % 32 == 0 && d->cout % 32 == 0, "conv: split-half tensors need c0, c1, cout %% 32 == 0 (got %d, %d, %d)", d->c0, d->c1, d->cout);
         MNET_CHECK_ALIGN(aligned128(d->x0) && aligned128(d->x1) && aligned128(d->wgt) && aligned128(d->y) && aligned128(d->residual),
@@ -460,7 +536,7 @@ static int conv_prepare(const mnet_conv_desc* d, int32_t algo, ConvArgs& a) {
     a.in_scale = d->in_scale; a.in_shift = d->in_shift; a.out_scale = d->out_scale; a.bias = d->bias;
     a.post_scale = d->post_scale;
     a.valid_w = d->valid_w;
-    a.c0 = d->c0 * cm; a.c1 = d->c1 * cm; a.cin = a.c0 + a.c1; a.split = split ? 1 : 0;
+    a.c0 = d->c0 * cm; a.c1 = d->c1 * cm; a.cin = a.c0 + a.c1; a.split = d->dtype == MNET_F16M ? 2 : (split ? 1 : 0);
     a.n = d->n; a.h = d->h; a.w = d->w; a.ho = d->ho; a.wo = d->wo; a.cout = d->cout;
     a.kh = d->kh; a.kw = d->kw; a.sh = d->stride_h; a.sw = d->stride_w; a.ph = d->pad_h; a.pw = d->pad_w;
     a.K = d->kh * d->kw * a.cin; a.npix = (int)npix; a.howo = d->ho * d->wo;
@@ -524,6 +600,7 @@ extern "C" int mnet_conv2d_nhwc_ex(const mnet_conv_desc* d, int32_t algo, void* 
     if (k >= MNET_CONV_ALGO_DMA_CFG0) return launch_conv_dma(a, st, k - MNET_CONV_ALGO_DMA_CFG0);
     if (k == MNET_CONV_ALGO_SKINNY) return launch_conv_skinny(a, st);
     if (d->dtype == MNET_F16X2) return launch_dtype<hs>(a, st);
+    if (d->dtype == MNET_F16M) return launch_dtype<hm>(a, st);
     return d->dtype == MNET_F16 ? launch_dtype<f16>(a, st) : launch_dtype<float>(a, st);
 }
 

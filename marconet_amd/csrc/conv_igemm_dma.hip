@@ -48,7 +48,7 @@ __global__ void __launch_bounds__(WC * WP * 64, WC * WP / 4) conv_dma_kernel(con
     constexpr int STAGE = (BC + BP) * 128;
     constexpr unsigned OOB = 0x80000000u;                // beyond every num_records used below
     static_assert(NW == 8 || NW == 16, "8 or 16 waves");
-    static_assert(!MX || (X3 && MF == 32 && STAGES == 2), "MX: 4-byte storage, 32x32 MFMAs, 2-stage tiles (plain vmcnt(0) waits)");
+    static_assert(!MX || (X3 && MF == 32), "MX: 4-byte storage, 32x32 MFMAs");
     static_assert(!SPREAD || (STAGES == 2 && (MF == 16 || X3) && DBG == 0), "SPREAD: production 2-stage tiles only");
     static_assert(WJ >= 1 && XJ >= 1 && WJ * 8 * NW == BC && XJ * 8 * NW == BP, "tile / wave-count mismatch");
     static_assert(STAGES == 2 || ((STAGES == 3 || STAGES == 4) && NDMA >= 4 && NDMA <= 6), "vmcnt immediates below cover 4-6 DMAs per slab, up to 3 slabs in flight");
@@ -109,7 +109,7 @@ __global__ void __launch_bounds__(WC * WP * 64, WC * WP / 4) conv_dma_kernel(con
 #pragma unroll
         for (int j = 0; j < WJ; ++j) {
             const int row = (wave + NW * j) * 8 + rg;
-            const int ch = dma_weight_channel<MF>(row);
+            const int ch = MX ? dma_weight_channel_mx(row) : dma_weight_channel<MF>(row);
             const int lc = pc ^ ((row >> 1) & 7);
             woff[j] = (co0 + ch < p.cout) ? (unsigned)(ch * p.K * 2 + lc * 16) : OOB;
         }
@@ -136,6 +136,7 @@ __global__ void __launch_bounds__(WC * WP * 64, WC * WP / 4) conv_dma_kernel(con
                 for (int r = 0; r < 8; ++r)
                     if (r < p.kh && (unsigned)(ih0 + r) < (unsigned)p.h) m |= cm << (r * p.kw);
                 xmask[j] = m;
+                if constexpr (MX) { if ((lcb >> 4) == 7u) xmask[j] = 0; }      // chunk 7 of an fp16+8 activation block is padding: not fetched
             }
         }
         cur_c = 0; cur_s = 0; cur_tap = 0; cur_tpx = 0; cur_k = 0;
@@ -485,7 +486,7 @@ __global__ void __launch_bounds__(WC * WP * 64, WC * WP / 4) conv_dma_kernel(con
             const unsigned char* wexp = reinterpret_cast<const unsigned char*>(p.wgt) + (size_t)p.cout * p.K * 2;
 #pragma unroll
             for (int f = 0; f < FC / 2; ++f) {
-                const int ch = co0 + dma_weight_channel<32>(wc * (BC / WC) + f * 32 + (lane & 31));
+                const int ch = co0 + dma_weight_channel_mx(wc * (BC / WC) + f * 32 + (lane & 31));
                 mx_sa[f] = ch < p.cout ? (int)wexp[ch] : 0;
             }
             drain = true;               // plain loads share the vmcnt counter with the DMA: the next wait is vmcnt(0)
@@ -539,7 +540,8 @@ __global__ void __launch_bounds__(WC * WP * 64, WC * WP / 4) conv_dma_kernel(con
 
         int co0, pix0;
         tile_coords(c_v, co0, pix0);
-        dma_epilogue<BC, BP, WC, WP, MF, DBG, FC, FP, X3>(p, acc, acc32, co0, pix0, wc, wp, lane);
+        if constexpr (MX) dma_epilogue_mx<BC, BP, WC, WP, FC, FP>(p, acc32, co0, pix0, wc, wp, lane);
+        else dma_epilogue<BC, BP, WC, WP, MF, DBG, FC, FP, X3>(p, acc, acc32, co0, pix0, wc, wp, lane);
         drain = true;
 
         if constexpr (DBG >= 3) {       // DIAGNOSTIC: overwrite part of the output with this tile's time stamps
@@ -588,6 +590,21 @@ static int launch_dma_cfg(const ConvArgs& a, hipStream_t st) {
 // ids 7-9: v_mfma_f32_32x32x16_f16 forms (fp32 sums associate differently).
 // ids 11-15: DIAGNOSTIC builds that produce wrong results on purpose (tools/wg_timeline.py, tools/conv_bench.py).
 static int launch_dma_id(int id, const ConvArgs& a, hipStream_t st) {
+    if (a.split == 2) { // fp16+8 (MNET_F16M) instantiations: the same tile shapes on 32x32 MFMAs
+        switch (id) {
+            case 0: return launch_dma_cfg<256, 256, 4, 4, 2, 32, 0, true, true, false, true>(a, st);
+            case 1: return launch_dma_cfg<256, 128, 4, 2, 3, 32, 0, true, false, false, true>(a, st);
+            case 2: return launch_dma_cfg<128, 256, 2, 4, 3, 32, 0, true, false, false, true>(a, st);
+            case 3: return launch_dma_cfg<64, 256, 1, 8, 3, 32, 0, true, false, false, true>(a, st);
+            case 4: return launch_dma_cfg<128, 512, 2, 8, 2, 32, 0, true, true, false, true>(a, st);
+            case 5: return launch_dma_cfg<64, 512, 1, 8, 2, 32, 0, true, true, false, true>(a, st);
+            case 6: return launch_dma_cfg<256, 256, 2, 4, 2, 32, 0, true, true, false, true>(a, st);          // 8 waves, 128x64 per wave: AUTO for cout >= 256
+            case 7: return launch_dma_cfg<128, 512, 2, 4, 2, 32, 0, true, true, false, true>(a, st);          // 8 waves, 64x128 per wave
+            case 8: return launch_dma_cfg<128, 512, 1, 8, 2, 32, 0, true, true, false, true>(a, st);          // 8 waves, 128x64 per wave
+            case 10: return launch_dma_cfg<128, 128, 2, 4, 4, 32, 0, true, false, false, true>(a, st);
+            default: return mnet_fail(MNET_E_ARG, "conv: LDS-DMA tile configuration %d has no fp16+8 form", id);
+        }
+    }
     if (a.split) {      // split-half (fp16x3) instantiations of the production tile configurations
         switch (id) {
             case 0: return launch_dma_cfg<256, 256, 4, 4, 2, 16, 0, true>(a, st);
@@ -605,9 +622,6 @@ static int launch_dma_id(int id, const ConvArgs& a, hipStream_t st) {
             case 10: return launch_dma_cfg<128, 128, 2, 4, 4, 16, 0, true>(a, st);
             case 20: return launch_dma_cfg<256, 256, 2, 4, 2, 32, 0, true, true>(a, st);          // id 8 on v_mfma_f32_32x32x16_f16
             case 21: return launch_dma_cfg<128, 512, 2, 4, 2, 32, 0, true, true>(a, st);          // id 9, same
-            case 24: return launch_dma_cfg<256, 256, 2, 4, 2, 32, 0, true, true, false, true>(a, st);   // fp16+8 (MX) operands, 256x256
-            case 25: return launch_dma_cfg<128, 512, 2, 4, 2, 32, 0, true, true, false, true>(a, st);   // fp16+8, 128x512
-            case 26: return launch_dma_cfg<64, 512, 1, 8, 2, 32, 0, true, true, false, true>(a, st);    // fp16+8, 64x512
             default: return mnet_fail(MNET_E_ARG, "conv: LDS-DMA tile configuration %d has no split-half form", id);
         }
     }
@@ -655,6 +669,13 @@ int conv_dma_pick(const ConvArgs& a) {
     // id 11 = id 8 with the LDS reads placed by scheduling hints (all hi fragments up front, the lo activation fragments under the
     // first group's MFMAs): 472 vs 465 TFLOP/s (+1.5 %); the 128x512 tile does not gain (id 12 stays an A/B knob)
     static const int env_x3_256 = [] { const char* e = getenv("MNET_X3_CFG256"); return e ? atoi(e) : 11; }();
+    if (a.split == 2) {
+        static const int env_mx_256 = [] { const char* e = getenv("MNET_MX_CFG256"); return e ? atoi(e) : 6; }();      // A/B knobs
+        static const int env_mx_128 = [] { const char* e = getenv("MNET_MX_CFG128"); return e ? atoi(e) : 8; }();
+        if (a.cout >= 256) return big ? env_mx_256 : (t128 * ((a.cout + 255) / 256) < 200 ? 10 : 1);
+        if (a.cout >= 128) return big ? env_mx_128 : (t256 * ((a.cout + 127) / 128) < 200 ? 10 : 2);
+        return big ? 5 : 3;
+    }
     if (a.split && big && a.cout >= 128) return env_x3_16w ? (a.cout >= 256 ? 0 : 4) : (a.cout >= 256 ? env_x3_256 : env_x3_128);
     // f16 big tiles: ids 8 / 9 = ids 0 / 4 with the next slab's DMA pieces issued between the two half slabs instead of right after
     // the barrier (+2.8 % on the 256x256 tile: 1140 vs 1109 TFLOP/s, B = 64; same MFMA sequence, same bits).  id 16 = the 8-wave
@@ -673,8 +694,8 @@ int launch_conv_dma(const ConvArgs& a, hipStream_t st, int cfg) {
 
 // eligibility of the LDS-DMA path (see header comment); the caller falls back to the register-staged kernel
 bool conv_dma_eligible(const ConvArgs& a, int dtype) {
-    if ((dtype != MNET_F16 && dtype != MNET_F16X2) || a.in_scale || a.act > MNET_ACT_LRELU_SQRT2) return false;
-    if (dtype == MNET_F16X2 && a.cout % 32 != 0) return false;          // (a.c0 / a.cin / a.K are physical here: f16 view, doubled)
+    if ((dtype != MNET_F16 && dtype != MNET_F16X2 && dtype != MNET_F16M) || a.in_scale || a.act > MNET_ACT_LRELU_SQRT2) return false;
+    if (dtype != MNET_F16 && a.cout % 32 != 0) return false;          // (a.c0 / a.cin / a.K are physical here: f16 view, doubled)
     if (a.cin % 64 != 0 || a.c0 % 64 != 0 || a.cout < 64 || a.cout % 8 != 0 || a.kh * a.kw > 32 || a.kh > 8 || a.kw > 8) return false;
     // 31-bit buffer offsets: a pixel tile may touch ceil(256/howo)+1 images
     const long long imgs = 512 / a.howo + 2;   // largest pixel tile is 512

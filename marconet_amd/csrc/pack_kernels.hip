@@ -50,15 +50,64 @@ __global__ void __launch_bounds__(256) pack_weights_kernel(const float* __restri
     }
 }
 
+// fp16+8 (MNET_F16M) conv weights, layout in include/marconet_hip.h: one workgroup per (padded) output channel — pass 1 the row's
+// max |f16(256 W)| → the row scale s = 2^(floor(log2 max) - 7); pass 2 one thread per 8-channel chunk: hi halves, lo8 = e4m3(lo * 2^11 / s),
+// hi8 = e4m3(hi / s); then the row's byte E8M0(s * 2^-11) after the cout_pad * K elements
+__global__ void __launch_bounds__(256) pack_weights_mx_kernel(const float* __restrict__ w, unsigned char* __restrict__ dst, int cout, int cin,
+                                                              int kh, int kw, int cout_pad, int cin_pad, float scale,
+                                                              const float* __restrict__ sigma) {
+    __shared__ float red[4];
+    const int o = blockIdx.x, t = threadIdx.x;
+    const float sg = sigma ? sigma[0] : 1.0f;
+    const int K = kh * kw * cin_pad;
+    auto value = [&](int k) -> float {
+        const int i = k % cin_pad, tap = k / cin_pad;
+        if (o >= cout || i >= cin) return 0.f;
+        float v = w[(((size_t)o * cin + i) * kh + tap / kw) * kw + tap % kw];
+        if (sigma) v = v / sg;
+        return v * scale;
+    };
+    float m = 0.f;
+    for (int k = t; k < K; k += 256) m = fmaxf(m, fabsf((float)(f16)value(k)));
+    m = wave_max(m);
+    if ((t & 63) == 0) red[t >> 6] = m;
+    __syncthreads();
+    m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    const int e8 = min(254, max(11, hm_e8_of(m)));
+    const float inv_hi = __builtin_bit_cast(float, (unsigned)(254 - e8) << 23);         // 1 / s
+    unsigned char* row = dst + (size_t)o * K * 4;
+    for (int ch = t; ch < K / 8; ch += 256) {
+        const int s = ch & 3;
+        unsigned char* blk = row + (size_t)(ch >> 2) * 128;
+        float v[8];
+        f16x8 h;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { v[j] = value(ch * 8 + j); h[j] = (f16)v[j]; }
+        stg16(blk + s * 16, bitcast<u32x4>(h));
+        u32x2 hi8;
+#pragma unroll
+        for (int d = 0; d < 2; ++d) {
+            int q = 0;
+            q = __builtin_amdgcn_cvt_pk_fp8_f32((float)h[4 * d] * inv_hi, (float)h[4 * d + 1] * inv_hi, q, false);
+            q = __builtin_amdgcn_cvt_pk_fp8_f32((float)h[4 * d + 2] * inv_hi, (float)h[4 * d + 3] * inv_hi, q, true);
+            hi8[d] = (unsigned)q;
+        }
+        unsigned char* f8 = blk + 64 + (s & 1) * 32 + (s >> 1) * 8;
+        *reinterpret_cast<u32x2*>(f8) = hm_encode_lo(v, h, e8);
+        *reinterpret_cast<u32x2*>(f8 + 16) = hi8;
+    }
+    if (t == 0) dst[(size_t)cout_pad * K * 4 + o] = (unsigned char)(e8 - 11);
+}
+
 extern "C" int mnet_pack_weights(const float* w_oihw, int32_t cout, int32_t cin, int32_t kh, int32_t kw, const float* sn_u,
                                  const float* sn_v, float scale, int32_t dtype, int32_t cout_pad, int32_t cin_pad, void* packed,
                                  double* workspace, void* stream) {
     MNET_CHECK_ARG(w_oihw && packed && cout > 0 && cin > 0 && kh > 0 && kw > 0, "pack_weights: bad args");
     MNET_CHECK_ARG(cout_pad >= cout && cin_pad >= cin, "pack_weights: padded sizes smaller than the tensor");
-    MNET_CHECK_ARG(dtype == MNET_F32 || dtype == MNET_F16 || dtype == MNET_F16X2, "pack_weights: bad dtype");
+    MNET_CHECK_ARG(dtype == MNET_F32 || dtype == MNET_F16 || dtype == MNET_F16X2 || dtype == MNET_F16M, "pack_weights: bad dtype");
     MNET_CHECK_ARG((sn_u == nullptr) == (sn_v == nullptr), "pack_weights: sn_u and sn_v go together");
     MNET_CHECK_ARG(!sn_u || workspace, "pack_weights: the spectral-norm fold needs a workspace of cout + 1 doubles");
-    MNET_CHECK_ALIGN(dtype != MNET_F16X2 || (cin_pad % 32 == 0 && aligned128(packed)), "pack_weights: split-half needs cin_pad %% 32 == 0, 128-byte aligned");
+    MNET_CHECK_ALIGN((dtype != MNET_F16X2 && dtype != MNET_F16M) || (cin_pad % 32 == 0 && aligned128(packed)), "pack_weights: split-half needs cin_pad %% 32 == 0, 128-byte aligned");
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     float* sigma = nullptr;
     if (sn_u) {
@@ -67,6 +116,12 @@ extern "C" int mnet_pack_weights(const float* w_oihw, int32_t cout, int32_t cin,
         MNET_LAUNCH_CHECK("sn_rowdot");
         hipLaunchKernelGGL(sn_fold_kernel, dim3(1), dim3(64), 0, st, workspace, cout, sigma);
         MNET_LAUNCH_CHECK("sn_fold");
+    }
+    if (dtype == MNET_F16M) {           // `packed` holds cout_pad * kh * kw * cin_pad * 4 + cout_pad bytes
+        hipLaunchKernelGGL(pack_weights_mx_kernel, dim3(cout_pad), dim3(256), 0, st, w_oihw, (unsigned char*)packed, cout, cin, kh, kw, cout_pad,
+                           cin_pad, scale * MNET_SPLIT_WSCALE, sigma);
+        MNET_LAUNCH_CHECK("pack_weights_mx");
+        return MNET_OK;
     }
     const long long total = (long long)cout_pad * kh * kw * cin_pad;
     const int blocks = (int)((total + 255) / 256 < 16384 ? (total + 255) / 256 : 16384);

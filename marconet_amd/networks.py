@@ -17,8 +17,8 @@ import torch.nn as nn
 
 from . import ops
 from .glyphs import GlyphTables
-from .packing import (PRECISIONS, SPLIT_DTYPE, PackCache, default_precision, equal_linear_scale, pack_conv_weight,
-                      pack_linear_weight, pack_vec, pack_wsq, rgb_pad, torch_dtype)
+from .packing import (PRECISIONS, SPLIT_DTYPE, PackCache, is_split, default_precision, equal_linear_scale, pack_conv_weight,
+                      pack_linear_weight, pack_vec, pack_wsq, padded_cout, rgb_pad, torch_dtype)
 from .resnet import resnet45stride as resnet45
 from .textvit_arch import TextViT as TextEncoder
 
@@ -178,7 +178,8 @@ class TextGenerator(nn.Module):
 
         def torgb(tr):
             mc = tr.conv
-            return dict(cin=mc.in_channel, w=pack_conv_weight(mc.weight.detach()[0], dtype, cout_mult=rgb_pad(dtype), scale=mc.scale),   # [3,Cin,1,1]
+            return dict(cin=mc.in_channel, cout=rgb_pad(dtype),
+                        w=pack_conv_weight(mc.weight.detach()[0], dtype, cout_mult=rgb_pad(dtype), scale=mc.scale),   # [3,Cin,1,1]
                         mod_w=pack_linear_weight(mc.modulation.weight, mc.modulation.scale), mod_b=f(mc.modulation.bias),
                         bias=pack_vec(tr.bias, rgb_pad(dtype)))
 
@@ -226,10 +227,10 @@ class TextGenerator(nn.Module):
                           out_scale=d, bias=L["bias"], act=ops.ACT_LRELU_SQRT2, post_scale=post, out=out)
 
     def _to_rgb(self, L, x, skip):
-        s, _, sb = self._mod(L, self._gidx, bcast=L["w"].shape[0])
+        s, _, sb = self._mod(L, self._gidx, bcast=L["cout"])
         if skip is not None:
             skip = ops.upsample2x(skip)                                        # :318-319
-        return ops.conv2d(x, L["w"], L["w"].shape[0], in_scale=s, out_scale=sb, bias=L["bias"], residual=skip, act=ops.ACT_TANH)
+        return ops.conv2d(x, L["w"], L["cout"], in_scale=s, out_scale=sb, bias=L["bias"], residual=skip, act=ops.ACT_TANH)
 
     def forward_nhwc(self, styles, labels, need_image=True, style_index=None, p64_out=None, p32_out=None):
         """→ (image NHWC [N,128,128c,8], prior64 NHWC [N,64,64c,256], prior32 NHWC [N,32,32c,512]).
@@ -377,7 +378,7 @@ class TSPSRNet(nn.Module, _Precision):
 
         def sn(name, m, cout_mult=4):
             w = pack_conv_weight(m.weight_orig.detach(), dtype, cout_mult=cout_mult, sn=(m.weight_u, m.weight_v))
-            cp = w.shape[0]                                    # padded cout (whole 32-channel blocks in the split-half mode)
+            cp = padded_cout(m.weight_orig.shape[0], dtype, cout_mult)   # whole 32-channel blocks in the split-half / fp16+8 modes
             pk[name] = dict(w=w, b=pack_vec(m.bias, cp), cout=cp, stride=(m.stride, m.stride))
 
         def res(name, m):
@@ -399,7 +400,7 @@ class TSPSRNet(nn.Module, _Precision):
         sn("conv_final.0", self.conv_final[0]); sn("conv_final.3", self.conv_final[3])
         res("conv_final.5", self.conv_final[5]); sn("conv_final.6", self.conv_final[6], cout_mult=rgb_pad(dtype))
         m6 = self.conv_final[6]                       # the same layer for the dedicated 64 → 3 kernel: [3][3][3][64], bias [3]
-        rgb_dt = torch.float32 if dtype == SPLIT_DTYPE else dtype          # (the split-half mode runs this 64 → 3 layer in fp32)
+        rgb_dt = torch.float32 if is_split(dtype) else dtype          # (the split-half mode runs this 64 → 3 layer in fp32)
         pk["conv_final.6.rgb"] = (pack_conv_weight(m6.weight_orig.detach(), rgb_dt, cin_mult=1, cout_mult=1, sn=(m6.weight_u, m6.weight_v)),
                                   m6.bias.detach().float().contiguous())
         res("conv_32_fuse.0", self.conv_32_fuse[0]); res("conv_64_fuse.0", self.conv_64_fuse[0])

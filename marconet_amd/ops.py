@@ -11,8 +11,8 @@ import torch
 
 from . import _lib
 from ._lib import (ACT_GELU, ACT_LRELU, ACT_LRELU_SQRT2, ACT_NONE, ACT_RELU, ACT_SIGMOID, ACT_TANH, MNET_F16,
-                   MNET_F16X2, MNET_F32, ConvDesc)
-from .packing import SPLIT_DTYPE
+                   MNET_F16M, MNET_F16X2, MNET_F32, ConvDesc)
+from .packing import MX_DTYPE, SPLIT_DTYPE, is_split, mx_weight_rows
 
 __all__ = ["conv2d", "linear", "nchw_to_nhwc", "nhwc_to_nchw", "upsample2x", "affine_act", "groupnorm_affine",
            "adain_crop_concat", "adain_crop_concat_gn", "glyph_scatter_affine", "layernorm", "token_mix", "attention", "pixelnorm",
@@ -28,6 +28,8 @@ def _dt(t):
         return MNET_F16
     if t.dtype == SPLIT_DTYPE:          # split half (fp16x3 mode): (hi, lo) per logical element, tagged as complex32
         return MNET_F16X2
+    if t.dtype == MX_DTYPE:             # fp16+8 (fp16x2 mode): hi half + e4m3 lo byte + block scale, tagged as uint32
+        return MNET_F16M
     raise TypeError("marconet_amd: unsupported dtype %s" % t.dtype)
 
 
@@ -60,7 +62,7 @@ def _need_cuda(*ts):
 def _raw(t):
     """split-half tensors are moved by PyTorch as plain halves (twice the channels): cat / index_select over the outer dimension
     never depend on the (experimental) complex32 support of an operator"""
-    return t.view(torch.float16) if t.dtype == SPLIT_DTYPE else t
+    return t.view(torch.float16) if is_split(t.dtype) else t
 
 
 def cat_rows(parts):
@@ -68,13 +70,13 @@ def cat_rows(parts):
     if len(parts) == 1:
         return parts[0]
     out = torch.cat([_raw(p) for p in parts], dim=0)
-    return out.view(SPLIT_DTYPE) if parts[0].dtype == SPLIT_DTYPE else out
+    return out.view(parts[0].dtype) if is_split(parts[0].dtype) else out
 
 
 def take_rows(t, idx):
     """t[idx] along dim 0 (any storage dtype)"""
     out = _raw(t).index_select(0, idx)
-    return out.view(SPLIT_DTYPE) if t.dtype == SPLIT_DTYPE else out
+    return out.view(t.dtype) if is_split(t.dtype) else out
 
 
 def on_device(t):
@@ -114,7 +116,10 @@ def conv2d(x0, wgt, cout, kh=1, kw=1, stride=(1, 1), pad=(0, 0), x1=None, in_sca
     _need_cuda(x0, x1, wgt, in_scale, in_shift, valid_w, out_scale, bias, residual, post_scale, out)
     n, h, w, c0 = x0.shape
     c1 = 0 if x1 is None else x1.shape[3]
-    if wgt.dtype != x0.dtype or (wgt.numel() != cout * kh * kw * (c0 + c1) and not (x0.dtype == SPLIT_DTYPE and wgt.numel() > cout * kh * kw * (c0 + c1))):
+    need = cout * kh * kw * (c0 + c1)
+    if x0.dtype == MX_DTYPE:            # + the per-output-channel scale bytes behind the weight rows
+        need = mx_weight_rows(cout, kh, kw, c0 + c1) * kh * kw * (c0 + c1)
+    if wgt.dtype != x0.dtype or wgt.numel() != need:
         raise RuntimeError("conv2d: weight dtype/shape mismatch (%s %s vs cout=%d k=%dx%d cin=%d)"
                            % (wgt.dtype, tuple(wgt.shape), cout, kh, kw, c0 + c1))
     ho = (h + 2 * pad[0] - kh) // stride[0] + 1
@@ -432,7 +437,8 @@ def pack_weights(w, dtype, cout_pad=None, cin_pad=None, scale=1.0, sn_u=None, sn
     _need_cuda(w, sn_u, sn_v)
     cout, cin, kh, kw = w.shape
     cout_pad, cin_pad = cout_pad or cout, cin_pad or cin
-    out = torch.empty((cout_pad, kh, kw, cin_pad), dtype=dtype, device=w.device)
+    rows = mx_weight_rows(cout_pad, kh, kw, cin_pad) if dtype == MX_DTYPE else cout_pad
+    out = (torch.zeros if dtype == MX_DTYPE else torch.empty)((rows, kh, kw, cin_pad), dtype=dtype, device=w.device)
     ws = torch.empty((cout + 1,), dtype=torch.float64, device=w.device) if sn_u is not None else None
     _lib.check(lib.mnet_pack_weights(_p(w), cout, cin, kh, kw, _p(sn_u), _p(sn_v), float(scale), _dt(out), cout_pad, cin_pad, _p(out),
                                      _p(ws), _stream()), "mnet_pack_weights")
@@ -471,7 +477,7 @@ def conv3x3_rgb(x, wgt, bias, act=ACT_TANH, nhwc=True, nchw=False):
     lib = _lib.load()
     _need_cuda(x, wgt, bias)
     n, h, w, c = x.shape
-    odt = torch.float32 if x.dtype == SPLIT_DTYPE else x.dtype       # split-half input: fp32 weights, fp32 outputs
+    odt = torch.float32 if is_split(x.dtype) else x.dtype            # split-half / fp16+8 input: fp32 weights, fp32 outputs
     if wgt.dtype != odt or wgt.numel() != 3 * 9 * c:
         raise RuntimeError("conv3x3_rgb: weight dtype/shape mismatch")
     y1 = torch.empty((n, h, w, 8), dtype=odt, device=x.device) if nhwc else None

@@ -18,8 +18,17 @@ import torch
 # bytes; the hi / lo halves are blocked per 32 channels, not interleaved per element).
 warnings.filterwarnings("ignore", message="ComplexHalf support is experimental")
 SPLIT_DTYPE = torch.complex32
+# MNET_F16M ("fp16+8", mode "fp16x2"; layout: mxfmt.py / include/marconet_hip.h) tensors are tagged with torch.uint32: again 4 bytes
+# per logical element, blocked per 32 channels; PyTorch only allocates, slices and concatenates them.
+MX_DTYPE = torch.uint32
 SPLIT_WSCALE = 256.0          # MNET_SPLIT_WSCALE: split-half conv weights hold hi/lo of 256*W (the conv rescales by 2^-8)
-PRECISIONS = ("fp32", "fp16", "fp16x3")
+PRECISIONS = ("fp32", "fp16", "fp16x3", "fp16x2")
+HALF_PRECISIONS = ("fp16", "fp16x3", "fp16x2")        # modes whose stored values are bounded by the fp16 range
+
+
+def is_split(dtype):
+    """the two 4-byte blocked storages (split half / fp16+8): 32-channel blocks, 128-byte aligned"""
+    return dtype == SPLIT_DTYPE or dtype == MX_DTYPE
 
 
 def default_precision():
@@ -33,15 +42,17 @@ def torch_dtype(precision):
     """storage dtype of the activations / conv weights of a precision mode:
     fp32 — exact fp32 MFMA (parity mode); fp16 — one half per element (throughput mode, ~1e-2 deviation);
     fp16x3 — split half (hi, lo) per element, x*w = hi*hi + hi*lo + lo*hi on the fp16 MFMA: fp32-class accuracy (meets the
-    1e-3 parity bar, argmax bit-exact) at a third of the fp16 MFMA rate instead of the fp32 MFMA's sixteenth."""
+    1e-3 parity bar, argmax bit-exact) at a third of the fp16 MFMA rate instead of the fp32 MFMA's sixteenth;
+    fp16x2 — "fp16+8": hi half + an e4m3 lo byte under a per-block scale, x*w = hi*hi (f16 MFMA) + one block-scaled fp8 MFMA for
+    both correction products: 2 MFMA units per product, ~16 significant bits (≈3e-4 end to end: inside the 1e-3 bar)."""
     if precision not in PRECISIONS:
         raise ValueError("precision must be one of %s" % ", ".join(PRECISIONS))
-    return {"fp32": torch.float32, "fp16": torch.float16, "fp16x3": SPLIT_DTYPE}[precision]
+    return {"fp32": torch.float32, "fp16": torch.float16, "fp16x3": SPLIT_DTYPE, "fp16x2": MX_DTYPE}[precision]
 
 
 def rgb_pad(dtype):
     """channel count 3-channel tensors are carried with: one 16-byte chunk of halves / floats, or one 32-channel split block"""
-    return 32 if dtype == SPLIT_DTYPE else 8
+    return 32 if is_split(dtype) else 8
 
 
 def split_halves(t):
@@ -59,6 +70,26 @@ def split_halves(t):
     return both.view(SPLIT_DTYPE).reshape(t.shape)
 
 
+def to_float(t):
+    """any storage dtype → fp32 (tests / debugging; host or device tensor)"""
+    if t.dtype == SPLIT_DTYPE:
+        return unsplit_halves(t)
+    if t.dtype == MX_DTYPE:
+        from . import mxfmt
+        return mxfmt.unpack_act(t.contiguous().view(torch.uint8), t.shape[-1])
+    return t.float()
+
+
+def from_float(t, dtype):
+    """fp32 [..., C] → storage dtype (host-side reference packers; tests)"""
+    if dtype == SPLIT_DTYPE:
+        return split_halves(t)
+    if dtype == MX_DTYPE:
+        from . import mxfmt
+        return mxfmt.pack_act(t).view(MX_DTYPE)
+    return t.to(dtype)
+
+
 def unsplit_halves(t):
     """inverse of split_halves (tests / debugging): split-half tensor → fp32"""
     c = t.shape[-1]
@@ -70,13 +101,19 @@ def _round_up(v, m):
     return (v + m - 1) // m * m
 
 
+def padded_cout(o, dtype, cout_mult=4):
+    """output channels of pack_conv_weight(w [o, ...], dtype, cout_mult=...) (whole 32-channel blocks in the 4-byte blocked modes);
+    for fp16+8 weights the packed tensor has MORE rows than this (the scale bytes): never read the channel count off its shape"""
+    return _round_up(o, max(cout_mult, 32) if is_split(dtype) else cout_mult)
+
+
 def pack_conv_weight(w, dtype, cin_mult=8, cout_mult=4, scale=1.0, sn=None):
     """w [O,I,KH,KW] fp32 → contiguous [O_pad,KH,KW,I_pad] in ``dtype`` (zero padded), every element (w / sigma) * scale.
     ``sn`` = (weight_u, weight_v): eval-mode old-style spectral norm, sigma = uᵀ(W_mat v) (models/networks.py:14).
     Parameters on a HIP device are packed by the library itself (mnet_pack_weights: no PyTorch arithmetic, no BLAS in the
     product process); host tensors (offline tooling, the CPU tests) take the equivalent torch path below."""
     o, i, kh, kw = w.shape
-    if dtype == SPLIT_DTYPE:            # whole 32-channel blocks on both sides
+    if is_split(dtype):                 # whole 32-channel blocks on both sides
         cin_mult, cout_mult = max(cin_mult, 32), max(cout_mult, 32)
     op, ip = _round_up(o, cout_mult), _round_up(i, cin_mult)
     if w.is_cuda:
@@ -94,7 +131,25 @@ def pack_conv_weight(w, dtype, cin_mult=8, cout_mult=4, scale=1.0, sn=None):
         w = wp
     if dtype == SPLIT_DTYPE:
         return split_halves(w.permute(0, 2, 3, 1).contiguous() * SPLIT_WSCALE)
+    if dtype == MX_DTYPE:
+        from . import mxfmt
+        return mx_weight_tensor(mxfmt.pack_weight(w.permute(0, 2, 3, 1).contiguous()), op, kh, kw, ip)
     return w.permute(0, 2, 3, 1).contiguous().to(dtype)
+
+
+def mx_weight_rows(cout_pad, kh, kw, cin_pad):
+    """rows of the [rows, kh, kw, cin_pad] tensor that holds packed fp16+8 conv weights: cout_pad weight rows + the rows that
+    carry the cout_pad per-channel scale bytes right behind them (include/marconet_hip.h)"""
+    row_bytes = kh * kw * cin_pad * 4
+    return cout_pad + (cout_pad + row_bytes - 1) // row_bytes
+
+
+def mx_weight_tensor(flat_u8, cout_pad, kh, kw, cin_pad):
+    """flat uint8 buffer of mxfmt.pack_weight → the [rows, kh, kw, cin_pad] MX_DTYPE tensor the conv wrappers take"""
+    rows = mx_weight_rows(cout_pad, kh, kw, cin_pad)
+    buf = torch.zeros((rows * kh * kw * cin_pad * 4,), dtype=torch.uint8, device=flat_u8.device)
+    buf[: flat_u8.numel()] = flat_u8
+    return buf.view(MX_DTYPE).reshape(rows, kh, kw, cin_pad)
 
 
 def pack_linear_weight(w, scale=1.0):
@@ -178,7 +233,7 @@ def equal_linear_scale(in_channels, lr_mul):
 # structure and the non-tensor leaves as JSON metadata, and a SHA-256 of each holder's parameters so that a blob is never
 # attached to different weights.
 PACK_FORMAT = "marconet_amd.packed.v2"
-PACK_LAYOUT = 3        # bump whenever any holder's _build() changes what it emits (keys, padding, layouts): a blob written by a
+PACK_LAYOUT = 4        # bump whenever any holder's _build() changes what it emits (keys, padding, layouts): a blob written by a
                        # different _build must not attach (it would fail with a KeyError mid-forward, or be read with another layout)
 
 
@@ -207,8 +262,8 @@ def _weights_digest(m):
 
 def _flatten(obj, path, tensors, tree):
     if torch.is_tensor(obj):
-        split = obj.dtype == SPLIT_DTYPE          # safetensors has no (hi, lo)-pair dtype: stored as the raw halves, re-tagged on load
-        tree[path] = {"t": "tensor", "split": split}
+        split = is_split(obj.dtype)               # safetensors has no such dtype: stored as the raw halves, re-tagged on load
+        tree[path] = {"t": "tensor", "split": split, "mx": obj.dtype == MX_DTYPE}
         t = obj.detach().contiguous().cpu()
         tensors[path] = (t.view(torch.float16) if split else t).clone()
     elif isinstance(obj, dict):
@@ -231,7 +286,7 @@ def _unflatten(path, get_tensor, tree):
     node = tree[path]
     if node["t"] == "tensor":
         t = get_tensor(path)
-        return t.view(SPLIT_DTYPE) if node.get("split") else t
+        return t.view(MX_DTYPE if node.get("mx") else SPLIT_DTYPE) if node.get("split") else t
     if node["t"] == "dict":
         return {k: _unflatten(path + "/" + k, get_tensor, tree) for k in node["keys"]}
     if node["t"] in ("tuple", "list"):

@@ -57,10 +57,16 @@ class MarconetPipeline:
         with ops.on_device(lq):
             lab, img_of = self._host_prep(labels, counts, dev)
             y = self._core(lq, lab, img_of, counts, locs, None, return_nhwc, output)
-            if self._checks() and self._finite is not None and not bool(self._finite):
-                raise FloatingPointError("marconet_amd: non-finite SR output in %s mode (half-precision overflow?) — use "
-                                         "precision='fp32' or 'fp16x3' for these weights" % self.precision)
+            self._raise_if_not_finite()
             return y
+
+    def _raise_if_not_finite(self):
+        """half-range modes (fp16 / fp16x3 / fp16x2 store |activation| < 65504): an overflow turns into NaN on its way through the
+        GroupNorm statistics of the following layers (and the last layer writes an infinite pre-activation as NaN instead of
+        tanh's +-1), so the SR result carries it; one flag is read back per batch."""
+        if self._checks() and self._finite is not None and not bool(self._finite):
+            raise FloatingPointError("marconet_amd: non-finite SR output in %s mode (activations beyond the fp16 range 65504?) — use "
+                                     "precision='fp32' for these weights" % self.precision)
 
     def _host_prep(self, labels, counts, dev):
         """labels (host or device) → validated device tensors (labels [ΣN,1], glyph→image index [ΣN])"""
@@ -147,6 +153,7 @@ class MarconetPipeline:
             img_of = torch.repeat_interleave(torch.arange(B, device=dev), torch.tensor(counts, device=dev))
             _, p64, p32 = tg.forward_nhwc(w.index_select(0, img_of).contiguous(), lab, need_image=self.need_prior_image)
         out = [None] * B
+        flags = []
         for wb in sorted(set(widths)):
             idx = [b for b in range(B) if widths[b] == wb]
             gsel = [g for b in idx for g in range(starts[b], starts[b + 1])]
@@ -164,8 +171,12 @@ class MarconetPipeline:
             else:
                 a = c = None
             y = self.sr.forward_packed(lq_b, a, c, cb, cb, None, nchw_out=True, tables=tables)
+            if self._checks():
+                flags.append(torch.isfinite(y).all())
             for k, b in enumerate(idx):
                 out[b] = y[k]
+        self._finite = torch.stack(flags).all() if flags else None
+        self._raise_if_not_finite()
         return out
 
 
@@ -316,6 +327,7 @@ class GraphedForward:
             GlyphTables(lh, counts, self.widths[0], 16, "cpu").copy_into(self.tables[0])
             GlyphTables(lh, counts, self.widths[1], 32, "cpu").copy_into(self.tables[1])
         self.graph.replay()
+        self.pipe._raise_if_not_finite()          # the flag tensor is part of the captured graph (refreshed by the replay)
         return self.out
 
 

@@ -192,19 +192,21 @@ def test_fp16_throughput_mode_deviation(nets, ckpts):
             m.set_precision("fp32")
 
 
+@pytest.mark.parametrize("prec", ["fp16x3", "fp16x2"])
 @pytest.mark.parametrize("name", ["grid", "full16", "edges"])
-def test_fp16x3_mode_meets_the_parity_bar(name, nets, ckpts, golden):
-    """the split-half throughput mode (three fp16 MFMA products per multiply) against the north-star bar itself:
+def test_fp16x3_mode_meets_the_parity_bar(name, prec, nets, ckpts, golden):
+    """the split-half (three fp16 MFMA products per multiply) and fp16+8 (f16 MFMA + one block-scaled fp8 MFMA) throughput modes
+    against the north-star bar itself:
     SR <= 1e-3 max-abs vs the CPU oracle AND vs the real reference's golden samples, character indices bit-exact"""
     lq, locs, labels = cases.sr_input(name)
     r = O.end_to_end(ckpts[0], ckpts[1], ckpts[2], lq, labels, locs)
     try:
         for m in nets:
-            m.set_precision("fp16x3")
+            m.set_precision(prec)
         logits, elocs, w = nets[0](lq.to(DEV))
         assert torch.equal(logits.argmax(-1).cpu(), r["logits"].argmax(-1))
-        _note("enc.fp16x3.%s.logits.maxabs" % name, _err(logits, r["logits"]))
-        _note("enc.fp16x3.%s.w.maxabs" % name, _err(w, r["w"]))
+        _note("enc." + prec + ".%s.logits.maxabs" % name, _err(logits, r["logits"]))
+        _note("enc." + prec + ".%s.w.maxabs" % name, _err(w, r["w"]))
         assert _err(logits, r["logits"]) <= TOL and _err(w, r["w"]) <= TOL and _err(elocs, r["enc_locs"]) <= TOL
         p64, p32 = [], []
         for b, lab in enumerate(labels):
@@ -212,12 +214,12 @@ def test_fp16x3_mode_meets_the_parity_bar(name, nets, ckpts, golden):
             p64.append(a)
             p32.append(c)
             if b == 0:
-                _note("gan.fp16x3.%s.image.maxabs" % name, _err(img, r["prior_images"][0]))
-                _note("gan.fp16x3.%s.prior64.maxabs" % name, _err(a, r["p64"][0]))
+                _note("gan." + prec + ".%s.image.maxabs" % name, _err(img, r["prior_images"][0]))
+                _note("gan." + prec + ".%s.prior64.maxabs" % name, _err(a, r["p64"][0]))
                 assert _err(img, r["prior_images"][0]) <= TOL and _err(a, r["p64"][0]) <= TOL
         y = nets[2](lq.to(DEV), p64, p32, locs.to(DEV))
         e = _err(y, r["sr"])
-        _note("sr.fp16x3.%s.chain.maxabs" % name, e)
+        _note("sr." + prec + ".%s.chain.maxabs" % name, e)
         assert torch.isfinite(y).all() and e <= TOL
         assert np.abs(cases.sample_map(y.cpu(), "sr").numpy() - golden["sr.%s.out_s" % name]).max() <= TOL
     finally:
@@ -225,21 +227,22 @@ def test_fp16x3_mode_meets_the_parity_bar(name, nets, ckpts, golden):
             m.set_precision("fp32")
 
 
-def test_fp16x3_batched_driver_and_batch_invariance(nets, ckpts):
+@pytest.mark.parametrize("prec", ["fp16x3", "fp16x2"])
+def test_fp16x3_batched_driver_and_batch_invariance(prec, nets, ckpts):
     """forward_batch in the fp16x3 mode on bench-shaped strips vs the oracle, and a batch == its halves bit for bit"""
     from marconet_amd.pipeline import MarconetPipeline
     counts, widths = [16, 7, 16, 12], [512, 512, 400, 512]
     lq = synth.make_lq(151, 4, widths)
     labels = [synth.make_labels(160 + b, c) for b, c in enumerate(counts)]
     locs = synth.make_locs(counts, widths, max_glyphs=16)
-    pipe = MarconetPipeline(*nets, precision="fp16x3")
+    pipe = MarconetPipeline(*nets, precision=prec)
     try:
         y = pipe.forward_batch(lq.to(DEV), labels, locs)
         worst = 0.0
         for b in range(4):
             r = O.end_to_end(ckpts[0], ckpts[1], ckpts[2], lq[b:b + 1], [labels[b]], locs[b:b + 1])
             worst = max(worst, _err(y[b:b + 1], r["sr"]))
-        _note("sr.fp16x3.forward_batch.bench_shape.maxabs", worst)
+        _note("sr." + prec + ".forward_batch.bench_shape.maxabs", worst)
         assert worst <= TOL
         lo = pipe.forward_batch(lq[:2].to(DEV), labels[:2], locs[:2])
         hi = pipe.forward_batch(lq[2:].to(DEV), labels[2:], locs[2:])
@@ -458,7 +461,7 @@ def test_forward_blind_vs_oracle(nets, ckpts):
     assert e <= TOL
 
 
-@pytest.mark.parametrize("precision", ["fp16", "fp16x3"])
+@pytest.mark.parametrize("precision", ["fp16", "fp16x3", "fp16x2"])
 def test_full_size_batch_properties_fp16(nets, precision):
     """BASELINE configs[1] at full size (64 strips x 16 glyphs, fp16 throughput mode), checked through size-independent
     properties instead of the (hours-long) CPU oracle: the batch equals its two halves run separately bit for bit (what
@@ -523,7 +526,7 @@ def test_generator_distinct_styles_equal_expanded(nets):
     nets[1].set_precision("fp32")
 
 
-@pytest.mark.parametrize("precision", ["fp16", "fp16x3", "fp32"])
+@pytest.mark.parametrize("precision", ["fp16", "fp16x3", "fp16x2", "fp32"])
 @pytest.mark.parametrize("output", ["nchw_f32", "u8_bgr"])
 def test_hip_graph_replay_equals_eager(nets, output, precision):
     """GraphedForward (the whole forward of one batch signature captured in a HIP graph) gives the eager driver's bits, also
@@ -546,7 +549,7 @@ def test_hip_graph_replay_equals_eager(nets, output, precision):
         pipe.set_precision("fp32")
 
 
-@pytest.mark.parametrize("precision", ["fp16", "fp16x3"])
+@pytest.mark.parametrize("precision", ["fp16", "fp16x3", "fp16x2"])
 def test_packed_blob_drives_the_same_forward(nets, ckpts, tmp_path, precision):
     """SURVEY §8(f) NEXT-3: modules that attach an offline packed-weights blob (packing.save_packed / load_packed) instead of
     packing at first use give the same bits"""
