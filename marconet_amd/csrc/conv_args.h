@@ -14,7 +14,6 @@ struct ConvArgs {
     int ktiles, tilesC, ntiles;
     int split;               // MNET_F16X2 launch: c0 / c1 / cin / K are PHYSICAL (f16 view with twice the channels: per 32-channel block 32 hi
                              // halves then 32 lo halves); cout stays logical; the epilogue multiplies the accumulator by 2^-8 and stores hi/lo
-    int mx_cvt;              // fp16+8 launches: how x_hi8 is produced (0: v_cvt_scalef32 with s, 1: with 1/s, 2: f16 multiply + unscaled cvt)
     int one_tile_per_wg;     // A/B knob (MNET_CONV_ALGO_FLAG_ONE_TILE): grid = #tiles instead of a persistent grid
 };
 

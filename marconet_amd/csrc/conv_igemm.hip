@@ -25,6 +25,9 @@
 #include "common.h"
 #include "conv_args.h"
 
+#ifndef MNET_MX_SCALED_DECODE
+#define MNET_MX_SCALED_DECODE 0      // 1: decode fp16+8 lo bytes with v_cvt_scalef32_pk_f16_fp8 (A/B build, EXTRA_HIPCC_FLAGS=-DMNET_MX_SCALED_DECODE=1)
+#endif
 
 template <typename T> struct Mma;
 template <> struct Mma<f16> {
@@ -57,9 +60,20 @@ template <> struct Phys<hm> { typedef f16 type; };      // fp16+8: staged into L
 // 128-byte block at `blk`, in split-half form — the lo bytes become halves (lo8 * s * 2^-11 is exact in f16 unless it underflows),
 // and the k-loop then runs the three-product split-half MFMA sequence unchanged.
 __device__ __forceinline__ u32x4 hm_lo_halves(u32x2 lo8, float sl) {
+#if MNET_MX_SCALED_DECODE
+    // v_cvt_scalef32_pk_f16_fp8: two e4m3 bytes -> two halves times 2^(exponent of sl), one instruction per pair
+    u32x4 r;
+#pragma unroll
+    for (int d = 0; d < 2; ++d) {
+        r[2 * d] = bitcast<unsigned>(__builtin_amdgcn_cvt_scalef32_pk_f16_fp8((int)lo8[d], sl, false));
+        r[2 * d + 1] = bitcast<unsigned>(__builtin_amdgcn_cvt_scalef32_pk_f16_fp8((int)lo8[d], sl, true));
+    }
+    return r;
+#else
     float l[8];
     hm_decode_lo(lo8, sl, l);
     return Vec<f16>::pack(l);
+#endif
 }
 __device__ __forceinline__ u32x4 ld_hm_act_chunk(const unsigned char* blk, int cc) {
     if (cc < 4) return ldg16(blk + cc * 16);
@@ -496,8 +510,6 @@ extern "C" double mnet_conv2d_flops(const mnet_conv_desc* d) {
 // argument validation shared by the launch and the planning entry points; fills the kernel-argument block
 static int conv_prepare(const mnet_conv_desc* d, int32_t algo, ConvArgs& a) {
     a.one_tile_per_wg = (algo & MNET_CONV_ALGO_FLAG_ONE_TILE) ? 1 : 0;
-    static const int env_mx_cvt = [] { const char* e = getenv("MNET_MX_CVT"); return e ? atoi(e) : 1; }();   // probe knob, see ConvArgs::mx_cvt
-    a.mx_cvt = env_mx_cvt;
     algo &= ~MNET_CONV_ALGO_FLAG_ONE_TILE;
     MNET_CHECK_ARG((algo >= 0 && algo <= 3) || (algo >= MNET_CONV_ALGO_DMA_CFG0 && algo < MNET_CONV_ALGO_DMA_CFG0 + 16) ||
                    (algo >= MNET_CONV_ALGO_STRIP_CFG0 && algo < MNET_CONV_ALGO_STRIP_CFG0 + 3) ||

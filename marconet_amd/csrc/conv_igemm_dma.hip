@@ -376,6 +376,8 @@ __global__ void __launch_bounds__(WC * WP * 64, WC * WP / 4) conv_dma_kernel(con
 
     // fp16+8 slab (see the MX note above the kernel)
     int mx_sa[MF == 32 ? FC / 2 : 1];                      // per weight fragment: E8M0 byte of s_w * 2^-11 for this lane's row (constant over k)
+    // PIPE: every LDS read of the slab is requested in program order up front and placed by scheduling hints — the f16 operands before
+    // the first MFMA, the fp8-side operands one per MFMA under the f16 products (their registers are the ones the first k-step frees)
     auto compute_mx = [&](int stage, auto&& between) __attribute__((always_inline)) {
         const unsigned char* sw_ = smem + stage * STAGE;
         const unsigned char* sx_ = sw_ + BC * 128;
@@ -389,7 +391,7 @@ __global__ void __launch_bounds__(WC * WP * 64, WC * WP / 4) conv_dma_kernel(con
 #pragma unroll
             for (int f = 0; f < FB; ++f) bh[k2][f] = *reinterpret_cast<const u32x4*>(sx_ + swz_dma(wp * (BP / WP) + f * 32 + l32, 2 * k2 + h));
         }
-        i32x8 b8[FB];
+        i32x8 b8[FB], a8[FA];
         int eb[FB];
 #pragma unroll
         for (int f = 0; f < FB; ++f) {
@@ -399,6 +401,14 @@ __global__ void __launch_bounds__(WC * WP * 64, WC * WP / 4) conv_dma_kernel(con
             const u32x4 lo8 = *reinterpret_cast<const u32x4*>(row + (((4 + h) ^ sw3) << 4));
             b8[f][4] = (int)lo8[0]; b8[f][5] = (int)lo8[1]; b8[f][6] = (int)lo8[2]; b8[f][7] = (int)lo8[3];
         }
+        if constexpr (PIPE) {
+#pragma unroll
+            for (int f = 0; f < FA; ++f) {
+                const u32x4 lo8 = *reinterpret_cast<const u32x4*>(sw_ + swz_dma(wc * (BC / WC) + f * 32 + l32, 4 + 2 * h));
+                const u32x4 hi8 = *reinterpret_cast<const u32x4*>(sw_ + swz_dma(wc * (BC / WC) + f * 32 + l32, 5 + 2 * h));
+                a8[f] = i32x8{(int)lo8[0], (int)lo8[1], (int)lo8[2], (int)lo8[3], (int)hi8[0], (int)hi8[1], (int)hi8[2], (int)hi8[3]};
+            }
+        }
 #pragma unroll
         for (int k2 = 0; k2 < 2; ++k2)
 #pragma unroll
@@ -406,35 +416,39 @@ __global__ void __launch_bounds__(WC * WP * 64, WC * WP / 4) conv_dma_kernel(con
 #pragma unroll
                 for (int fb = 0; fb < FB; ++fb)
                     acc32[fa][fb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bitcast<f16x8>(a[k2][fa]), bitcast<f16x8>(bh[k2][fb]), acc32[fa][fb], 0, 0, 0);
+        if constexpr (PIPE) {
+            constexpr int NF16 = 2 * (FA + FB), NF8 = 2 * FB + 2 * FA, NM = 2 * FA * FB;     // DS reads: f16 operands / fp8-side operands; f16 MFMAs
+            __builtin_amdgcn_sched_group_barrier(0x100, NF16, 0);
+#pragma unroll
+            for (int i = 0; i < (NF8 < NM ? NF8 : NM); ++i) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+            }
+            if constexpr (NM > NF8) __builtin_amdgcn_sched_group_barrier(0x008, NM - NF8, 0);
+        }
         between();
         // x_hi8 of this lane's 16 channels (the two f16 chunks it holds): e4m3(hi / s_x)
 #pragma unroll
         for (int f = 0; f < FB; ++f) {
-            const int e = eb[f];
+            const float sc = __builtin_bit_cast(float, (unsigned)eb[f] << 23);       // s_x = 2^(E - 127) (only the exponent field of the operand is used: E = 0, an all-zero / out-of-range row, gives 0)
 #pragma unroll
             for (int k2 = 0; k2 < 2; ++k2)
 #pragma unroll
                 for (int d = 0; d < 2; ++d) {
+                    // v_cvt_scalef32_pk_fp8_f16 DIVIDES by its scale operand (measured: tools/mx_spike.py, profiles/r3a_mx_spike.txt)
                     s16x2 r = {0, 0};
-                    if (p.mx_cvt == 2) {            // exact power-of-two multiply, then an unscaled conversion
-                        const f16 m = (f16)__builtin_bit_cast(float, (unsigned)(254 - e) << 23);
-                        const f16x2 mm = {m, m};
-                        r = __builtin_amdgcn_cvt_scalef32_pk_fp8_f16(r, bitcast<f16x2>(bh[k2][f][2 * d]) * mm, 1.0f, false);
-                        r = __builtin_amdgcn_cvt_scalef32_pk_fp8_f16(r, bitcast<f16x2>(bh[k2][f][2 * d + 1]) * mm, 1.0f, true);
-                    } else {
-                        const float sc = __builtin_bit_cast(float, (unsigned)(p.mx_cvt ? 254 - e : e) << 23);
-                        r = __builtin_amdgcn_cvt_scalef32_pk_fp8_f16(r, bitcast<f16x2>(bh[k2][f][2 * d]), sc, false);
-                        r = __builtin_amdgcn_cvt_scalef32_pk_fp8_f16(r, bitcast<f16x2>(bh[k2][f][2 * d + 1]), sc, true);
-                    }
+                    r = __builtin_amdgcn_cvt_scalef32_pk_fp8_f16(r, bitcast<f16x2>(bh[k2][f][2 * d]), sc, false);
+                    r = __builtin_amdgcn_cvt_scalef32_pk_fp8_f16(r, bitcast<f16x2>(bh[k2][f][2 * d + 1]), sc, true);
                     b8[f][2 * k2 + d] = bitcast<int>(r);
                 }
         }
-        i32x8 a8[FA];
+        if constexpr (!PIPE) {
 #pragma unroll
-        for (int f = 0; f < FA; ++f) {
-            const u32x4 lo8 = *reinterpret_cast<const u32x4*>(sw_ + swz_dma(wc * (BC / WC) + f * 32 + l32, 4 + 2 * h));
-            const u32x4 hi8 = *reinterpret_cast<const u32x4*>(sw_ + swz_dma(wc * (BC / WC) + f * 32 + l32, 5 + 2 * h));
-            a8[f] = i32x8{(int)lo8[0], (int)lo8[1], (int)lo8[2], (int)lo8[3], (int)hi8[0], (int)hi8[1], (int)hi8[2], (int)hi8[3]};
+            for (int f = 0; f < FA; ++f) {
+                const u32x4 lo8 = *reinterpret_cast<const u32x4*>(sw_ + swz_dma(wc * (BC / WC) + f * 32 + l32, 4 + 2 * h));
+                const u32x4 hi8 = *reinterpret_cast<const u32x4*>(sw_ + swz_dma(wc * (BC / WC) + f * 32 + l32, 5 + 2 * h));
+                a8[f] = i32x8{(int)lo8[0], (int)lo8[1], (int)lo8[2], (int)lo8[3], (int)hi8[0], (int)hi8[1], (int)hi8[2], (int)hi8[3]};
+            }
         }
 #pragma unroll
         for (int fa = 0; fa < FA; ++fa)
@@ -602,6 +616,9 @@ static int launch_dma_id(int id, const ConvArgs& a, hipStream_t st) {
             case 7: return launch_dma_cfg<128, 512, 2, 4, 2, 32, 0, true, true, false, true>(a, st);          // 8 waves, 64x128 per wave
             case 8: return launch_dma_cfg<128, 512, 1, 8, 2, 32, 0, true, true, false, true>(a, st);          // 8 waves, 128x64 per wave
             case 10: return launch_dma_cfg<128, 128, 2, 4, 4, 32, 0, true, false, false, true>(a, st);
+            case 11: return launch_dma_cfg<256, 256, 2, 4, 2, 32, 0, true, true, true, true>(a, st);          // id 6 + LDS reads placed by scheduling hints
+            case 12: return launch_dma_cfg<128, 512, 1, 8, 2, 32, 0, true, true, true, true>(a, st);          // id 8, same
+            case 13: return launch_dma_cfg<64, 512, 1, 8, 2, 32, 0, true, true, true, true>(a, st);           // id 5, same
             default: return mnet_fail(MNET_E_ARG, "conv: LDS-DMA tile configuration %d has no fp16+8 form", id);
         }
     }

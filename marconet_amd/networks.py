@@ -55,8 +55,11 @@ class TextContextEncoderV2(nn.Module, _Precision):
 
     def forward(self, lq):
         with torch.no_grad(), ops.on_device(lq):
-            self.resnet.precision = self.precision
-            dtype = torch_dtype(self.precision)
+            # "fp16x2" (fp16+8 operands, ~1e-4 on the logits): the ResNet keeps the three-product split-half arithmetic — it is 5 % of the
+            # path's FLOPs, its logits decide the character indices (argmax over near ties) and its style vector w feeds every modulation
+            rp = "fp16x3" if self.precision == "fp16x2" else self.precision
+            self.resnet.precision = rp
+            dtype = torch_dtype(rp)
             x = ops.nchw_to_nhwc(lq.contiguous().float(), dtype, c_ld=rgb_pad(dtype))
             feat = self.resnet.forward_nhwc(x)
             feat = ops.convert(feat, torch.float32)          # the ViT always runs in fp32

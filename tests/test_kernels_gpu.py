@@ -24,25 +24,49 @@ def _rnd(shape, seed, scale=1.0):
     return torch.randn(shape, generator=g) * scale
 
 
+def _P():
+    from marconet_amd import packing
+    return packing
+
+
+# the two 4-byte blocked storages (split half: 22 significant bits; fp16+8: ~16 bits relative to the largest value of a 32-channel
+# block) go through the HOST packers of marconet_amd/packing.py / mxfmt.py — independent of the device converter
+SPLIT, MX = "split", "mx"
+ALL_DTYPES = [torch.float32, torch.float16, SPLIT, MX]
+
+
+def _dt(dtype):
+    return {SPLIT: _P().SPLIT_DTYPE, MX: _P().MX_DTYPE}.get(dtype, dtype)
+
+
 def _q(t, dtype):
-    """round through the storage dtype (identity for fp32)"""
+    """round an NCHW tensor through the storage dtype (identity for fp32)"""
+    if dtype in (SPLIT, MX):
+        P = _P()
+        return P.to_float(P.from_float(t.permute(0, 2, 3, 1).contiguous(), _dt(dtype))).permute(0, 3, 1, 2).contiguous()
     return t.to(dtype).float()
 
 
 def _nhwc(t, dtype):   # NCHW cpu fp32 -> NHWC device
+    if dtype in (SPLIT, MX):
+        return _P().from_float(t.permute(0, 2, 3, 1).contiguous(), _dt(dtype)).to(DEV)
     return t.permute(0, 2, 3, 1).contiguous().to(dtype).to(DEV)
 
 
 def _nchw(t):          # NHWC device -> NCHW cpu fp32
+    if _P().is_split(t.dtype):
+        return _P().to_float(t.cpu()).permute(0, 3, 1, 2).contiguous()
     return t.float().cpu().permute(0, 3, 1, 2).contiguous()
 
 
 def _pack_w(w, dtype):  # OIHW -> [O,KH,KW,I]
+    if dtype in (SPLIT, MX):
+        return _P().pack_conv_weight(w, _dt(dtype)).to(DEV)
     return w.permute(0, 2, 3, 1).contiguous().to(dtype).to(DEV)
 
 
 def _tol(dtype):
-    return 2e-5 if dtype == torch.float32 else 2.5e-3
+    return {torch.float32: 2e-5, torch.float16: 2.5e-3, SPLIT: 2e-6, MX: 2e-5}[dtype]
 
 
 def _check(name, got, ref, dtype, extra=1.0):
@@ -183,17 +207,17 @@ def test_layout_roundtrip(dtype):
     assert torch.equal(ops.nhwc_to_nchw(y2).cpu(), _q(x2, dtype))
 
 
-@pytest.mark.parametrize("dtype", [torch.float32, torch.float16])
+@pytest.mark.parametrize("dtype", ALL_DTYPES)
 def test_upsample2x(dtype):
     ops = _ops()
-    x = _q(_rnd((2, 16, 5, 7), 21), dtype)
+    x = _q(_rnd((2, 32, 5, 7), 21), dtype)
     ref = F.interpolate(x, scale_factor=2, mode="bilinear", align_corners=False)
     y = ops.upsample2x(_nhwc(x, dtype))
     torch.cuda.synchronize()
     _check("upsample2x %s" % dtype, _nchw(y), ref, dtype)
 
 
-@pytest.mark.parametrize("dtype", [torch.float32, torch.float16])
+@pytest.mark.parametrize("dtype", ALL_DTYPES)
 @pytest.mark.parametrize("c", [64, 256, 512])
 def test_groupnorm_affine(c, dtype):
     ops = _ops()
@@ -210,7 +234,7 @@ def test_groupnorm_affine(c, dtype):
         _check("groupnorm c=%d img=%d %s" % (c, i, dtype), got, ref, torch.float32, extra=2.0)
 
 
-@pytest.mark.parametrize("dtype", [torch.float32, torch.float16])
+@pytest.mark.parametrize("dtype", ALL_DTYPES)
 @pytest.mark.parametrize("S", [32, 64])
 def test_adain_crop_and_scatter(S, dtype):
     ops = _ops()
@@ -241,11 +265,11 @@ def test_adain_crop_and_scatter(S, dtype):
     out3, gsc3, gsh3 = ops.adain_crop_concat_gn(_nhwc(prior, dtype), _nhwc(feat, dtype), g_img.to(DEV), g_x1.to(DEV), g_y1.to(DEV),
                                                 g_w.to(DEV), gamma.to(DEV), beta.to(DEV), 1e-6, split=True)
     torch.cuda.synchronize()
-    assert torch.equal(out2, out)
-    ulp = 1e-3 if dtype == torch.float16 else 2e-7
-    assert torch.allclose(out3.float(), out.float(), rtol=ulp, atol=ulp)
+    assert torch.equal(_nchw(out2), got)
+    ulp = {torch.float16: 1e-3, MX: 1e-4}.get(dtype, 2e-7)
+    assert torch.allclose(_nchw(out3), got, rtol=ulp, atol=ulp)
     assert torch.allclose(gsc3, gsc, rtol=1e-6, atol=1e-7) and torch.allclose(gsh3, gsh, rtol=1e-6, atol=1e-6)
-    print("adain split == fused bit for bit:", bool(torch.equal(out3, out) and torch.equal(gsc3, gsc) and torch.equal(gsh3, gsh)))
+    print("adain split == fused bit for bit:", bool(torch.equal(_nchw(out3), got) and torch.equal(gsc3, gsc) and torch.equal(gsh3, gsh)))
     for g, (b, x1, gw) in enumerate(windows):
         y1 = int(g_y1[g])
         cp, cl = prior[g:g + 1, :, :, y1:y1 + gw], feat[b:b + 1, :, :, x1:x1 + gw]
@@ -334,18 +358,19 @@ def test_gan_small_ops():
     assert torch.equal(ops.convert(h, torch.float32).cpu(), xx.half().float())
 
 
-@pytest.mark.parametrize("dtype", [torch.float32, torch.float16])
+@pytest.mark.parametrize("dtype", ALL_DTYPES)
 def test_post_scale_upsample_scale_affine_act(dtype):
     ops = _ops()
-    n, h, w, cin, cout = 3, 6, 10, 32, 40
+    n, h, w, cin, cout = 3, 6, 10, 32, 64 if dtype in (SPLIT, MX) else 40
     x = _q(_rnd((n, cin, h, w), 50), dtype)
-    wt = _q(_rnd((cout, cin, 3, 3), 51, 1.0 / math.sqrt(cin * 9)), dtype)
+    wt = _rnd((cout, cin, 3, 3), 51, 1.0 / math.sqrt(cin * 9))
+    wt = wt if dtype in (SPLIT, MX) else _q(wt, dtype)          # (the blocked storages pack 256 W: the reference keeps the true weights)
     bias, osc, post = _rnd((cout,), 52, 0.3), _rnd((n, cout), 53).abs() + 0.5, _rnd((n, cout), 54) + 1.0
     ref = F.leaky_relu(F.conv2d(x, wt, padding=1) * osc[:, :, None, None] + bias[None, :, None, None], 0.2) * 2 ** 0.5
     ref = ref * post[:, :, None, None]
     y = ops.conv2d(_nhwc(x, dtype), _pack_w(wt, dtype), cout, 3, 3, (1, 1), (1, 1), out_scale=osc.to(DEV), bias=bias.to(DEV),
                    act=ops.ACT_LRELU_SQRT2, post_scale=post.to(DEV))
-    _check("conv post_scale %s" % dtype, _nchw(y), ref, dtype, extra=2.0)
+    _check("conv post_scale %s" % dtype, _nchw(y), ref, dtype, extra={SPLIT: 4.0, MX: 2.5}.get(dtype, 2.0))
     sc = _rnd((n, cin), 55) + 1.0
     ref = F.interpolate(x, scale_factor=2, mode="bilinear", align_corners=False) * sc[:, :, None, None]
     _check("upsample2x*scale %s" % dtype, _nchw(ops.upsample2x(_nhwc(x, dtype), scale=sc.to(DEV))), ref, dtype)

@@ -114,9 +114,11 @@ def test_convert_round_trip_and_layout():
     assert ((back - x).abs() <= blockmax * 2.0 ** -15 + 1e-30).all()   # hi half + 4-bit lo under the block scale
     h = ops.convert(ops.convert(s, torch.float16), torch.float32).cpu()             # fp16+8 → plain half
     assert torch.equal(h, back.to(torch.float16).float())
-    s3 = ops.convert(s, P.SPLIT_DTYPE)                                              # → split half: exact (16 bits fit in 22)
-    assert torch.equal(ops.convert(s3, torch.float32).cpu(), back)
-    assert torch.equal(ops.convert(s3, P.MX_DTYPE).cpu().view(torch.uint8), host)   # and back
+    s3 = ops.convert(s, P.SPLIT_DTYPE)                                              # → split half: exact up to the f16 subnormal step of lo
+    assert float((ops.convert(s3, torch.float32).cpu() - back).abs().max()) <= 2.0 ** -25
+    big = _rnd((2, 4, 4, 32), 7) * 8.0 + 16.0                                       # every lo well inside the f16 normal range: exact both ways
+    sb = ops.convert(big.to(DEV), P.MX_DTYPE)
+    assert torch.equal(ops.convert(ops.convert(sb, P.SPLIT_DTYPE), P.MX_DTYPE).cpu().view(torch.uint8), sb.cpu().view(torch.uint8))
 
 
 def test_layout_kernels_nchw():
