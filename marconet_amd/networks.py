@@ -53,11 +53,21 @@ class TextContextEncoderV2(nn.Module, _Precision):
         self.precision = default_precision()
         self.resnet.precision = self.precision
 
+    @staticmethod
+    def resnet_precision(precision):
+        """"fp16x2" (fp16+8 operands, ~3e-4 on the logits when the ResNet runs in it): the ResNet keeps the three-product split-half
+        arithmetic — it is 5 % of the path's FLOPs, its logits decide the character indices (argmax over near ties) and its style
+        vector w feeds every modulation of the generator"""
+        return "fp16x3" if precision == "fp16x2" else precision
+
+    def set_precision(self, precision):
+        _Precision.set_precision(self, precision)
+        self.resnet.precision = self.resnet_precision(precision)
+        return self
+
     def forward(self, lq):
         with torch.no_grad(), ops.on_device(lq):
-            # "fp16x2" (fp16+8 operands, ~1e-4 on the logits): the ResNet keeps the three-product split-half arithmetic — it is 5 % of the
-            # path's FLOPs, its logits decide the character indices (argmax over near ties) and its style vector w feeds every modulation
-            rp = "fp16x3" if self.precision == "fp16x2" else self.precision
+            rp = self.resnet_precision(self.precision)
             self.resnet.precision = rp
             dtype = torch_dtype(rp)
             x = ops.nchw_to_nhwc(lq.contiguous().float(), dtype, c_ld=rgb_pad(dtype))

@@ -5,6 +5,7 @@ Activations are NHWC torch tensors of shape [N,H,W,C] and dtype float32, float16
 mode (MNET_F16X2) — packing.SPLIT_DTYPE (a 4-byte tag: a (hi, lo) pair of halves per logical element, C % 32 == 0).
 """
 import ctypes
+import functools
 import os
 
 import torch
@@ -12,13 +13,23 @@ import torch
 from . import _lib
 from ._lib import (ACT_GELU, ACT_LRELU, ACT_LRELU_SQRT2, ACT_NONE, ACT_RELU, ACT_SIGMOID, ACT_TANH, MNET_F16,
                    MNET_F16M, MNET_F16X2, MNET_F32, ConvDesc)
-from .packing import MX_DTYPE, SPLIT_DTYPE, is_split, mx_weight_rows
+from .packing import MX_DTYPE, SPLIT_DTYPE, is_split, mx_weight_rows, new_tensor, tag, untag
 
 __all__ = ["conv2d", "linear", "nchw_to_nhwc", "nhwc_to_nchw", "upsample2x", "affine_act", "groupnorm_affine",
            "adain_crop_concat", "adain_crop_concat_gn", "glyph_scatter_affine", "layernorm", "token_mix", "attention", "pixelnorm",
            "embed_gather", "demod", "argmax_rows", "convert", "fused_bias_act", "sr_postprocess", "conv3x3_rgb", "stats",
            "pack_weights", "pack_wsq", "gather_rows", "style_rows",
            "ACT_NONE", "ACT_RELU", "ACT_LRELU", "ACT_LRELU_SQRT2", "ACT_TANH", "ACT_GELU", "ACT_SIGMOID"]
+
+
+def _plumbing(fn):
+    """kernel wrappers read shapes / dtypes / pointers of blocked-storage tensors many times per launch: inside a wrapper the
+    BlockedTensor guard (packing.BlockedTensor.__torch_function__, ~2.5 us per access) is switched off; outputs are tagged again"""
+    @functools.wraps(fn)
+    def wrapper(*args, **kwargs):
+        with torch._C.DisableTorchFunctionSubclass():
+            return fn(*args, **kwargs)
+    return wrapper
 
 
 def _dt(t):
@@ -62,21 +73,23 @@ def _need_cuda(*ts):
 def _raw(t):
     """split-half tensors are moved by PyTorch as plain halves (twice the channels): cat / index_select over the outer dimension
     never depend on the (experimental) complex32 support of an operator"""
-    return t.view(torch.float16) if is_split(t.dtype) else t
+    return untag(t).view(torch.float16) if is_split(t.dtype) else t
 
 
+@_plumbing
 def cat_rows(parts):
     """concatenation of NHWC tensors along dim 0 (any storage dtype)"""
     if len(parts) == 1:
         return parts[0]
     out = torch.cat([_raw(p) for p in parts], dim=0)
-    return out.view(parts[0].dtype) if is_split(parts[0].dtype) else out
+    return tag(out.view(parts[0].dtype)) if is_split(parts[0].dtype) else out
 
 
+@_plumbing
 def take_rows(t, idx):
     """t[idx] along dim 0 (any storage dtype)"""
     out = _raw(t).index_select(0, idx)
-    return out.view(t.dtype) if is_split(t.dtype) else out
+    return tag(out.view(t.dtype)) if is_split(t.dtype) else out
 
 
 def on_device(t):
@@ -107,6 +120,7 @@ class _Stats:
 stats = _Stats()
 
 
+@_plumbing
 def conv2d(x0, wgt, cout, kh=1, kw=1, stride=(1, 1), pad=(0, 0), x1=None, in_scale=None, in_shift=None,
            in_swish=False, valid_w=None, out_scale=None, bias=None, residual=None, res_mod=0, act=ACT_NONE,
            post_scale=None, out=None, algo=0, splitk=0):
@@ -125,7 +139,7 @@ def conv2d(x0, wgt, cout, kh=1, kw=1, stride=(1, 1), pad=(0, 0), x1=None, in_sca
     ho = (h + 2 * pad[0] - kh) // stride[0] + 1
     wo = (w + 2 * pad[1] - kw) // stride[1] + 1
     if out is None:
-        out = torch.empty((n, ho, wo, cout), dtype=x0.dtype, device=x0.device)
+        out = new_tensor((n, ho, wo, cout), x0.dtype, x0.device)
     elif tuple(out.shape) != (n, ho, wo, cout) or out.dtype != x0.dtype:
         raise RuntimeError("conv2d: out is %s %s, expected %s %s" % (tuple(out.shape), out.dtype, (n, ho, wo, cout), x0.dtype))
     d = ConvDesc()
@@ -187,6 +201,7 @@ def linear(x, wgt, out_features, bias=None, act=ACT_NONE, residual=None, res_mod
     return y.reshape(m, out_features)
 
 
+@_plumbing
 def nchw_to_nhwc(src, dtype, c_ld=None):
     lib = _lib.load()
     _need_cuda(src)
@@ -194,11 +209,12 @@ def nchw_to_nhwc(src, dtype, c_ld=None):
         raise TypeError("nchw_to_nhwc: fp32 NCHW input expected (the reference's tensors are fp32)")
     n, c, h, w = src.shape
     c_ld = c_ld or c
-    dst = torch.empty((n, h, w, c_ld), dtype=dtype, device=src.device)
+    dst = new_tensor((n, h, w, c_ld), dtype, src.device)
     _lib.check(lib.mnet_nchw_to_nhwc(_p(src), _p(dst), _dt(dst), n, c, h, w, c_ld, _stream()), "mnet_nchw_to_nhwc")
     return dst
 
 
+@_plumbing
 def nhwc_to_nchw(src, c=None):
     lib = _lib.load()
     _need_cuda(src)
@@ -209,28 +225,31 @@ def nhwc_to_nchw(src, c=None):
     return dst
 
 
+@_plumbing
 def upsample2x(src, scale=None):
     """bilinear x2 (align_corners=False); optional per-(n,c) fp32 multiplier fused into the store"""
     lib = _lib.load()
     _need_cuda(src, scale)
     n, h, w, c = src.shape
-    dst = torch.empty((n, 2 * h, 2 * w, c), dtype=src.dtype, device=src.device)
+    dst = new_tensor((n, 2 * h, 2 * w, c), src.dtype, src.device)
     _lib.check(lib.mnet_upsample2x_scale_nhwc(_p(src), _p(dst), _dt(src), n, h, w, c, _p(scale), _stream()),
                "mnet_upsample2x_scale_nhwc")
     return dst
 
 
+@_plumbing
 def affine_act(x, scale, shift=None, swish=False, out=None):
     """y = f(x*scale[n,c] + shift[n,c]) elementwise over NHWC x [N,H,W,C] (GroupNorm apply + swish)."""
     lib = _lib.load()
     _need_cuda(x, scale, shift, out)
     n, h, w, c = x.shape
-    y = torch.empty_like(x) if out is None else out
+    y = tag(torch.empty_like(x)) if out is None else out
     _lib.check(lib.mnet_affine_act_nhwc(_p(x), _p(y), _dt(x), n, h * w, c, _p(scale), _p(shift), 1 if swish else 0,
                                         _stream()), "mnet_affine_act_nhwc")
     return y
 
 
+@_plumbing
 def groupnorm_affine(x, gamma, beta, eps=1e-6, valid_w=None):
     """→ (scale [N,C], shift [N,C]) fp32 for conv2d(in_scale=, in_shift=, in_swish=True)."""
     lib = _lib.load()
@@ -245,6 +264,7 @@ def groupnorm_affine(x, gamma, beta, eps=1e-6, valid_w=None):
     return scale, shift
 
 
+@_plumbing
 def adain_crop_concat(prior, feat, g_img, g_x1, g_y1, g_w):
     lib = _lib.load()
     _need_cuda(prior, feat, g_img, g_x1, g_y1, g_w)
@@ -252,7 +272,7 @@ def adain_crop_concat(prior, feat, g_img, g_x1, g_y1, g_w):
     B, FH, FW, FC = feat.shape
     if S != S2 or FH != S or FC != C or prior.dtype != feat.dtype:
         raise RuntimeError("adain_crop_concat: shape mismatch prior %s feat %s" % (tuple(prior.shape), tuple(feat.shape)))
-    out = torch.empty((G, S, S, 2 * C), dtype=prior.dtype, device=prior.device)
+    out = new_tensor((G, S, S, 2 * C), prior.dtype, prior.device)
     _lib.check(lib.mnet_adain_crop_concat(_p(prior), _p(feat), _p(out), _dt(prior), G, S, C, FW, _p(g_img), _p(g_x1),
                                           _p(g_y1), _p(g_w), _stream()), "mnet_adain_crop_concat")
     return out
@@ -262,6 +282,7 @@ ADAIN_SPLIT_BELOW = 256      # glyphs per launch below which the three-launch (1
 _ADAIN_SPLIT = {"0": False, "1": True}.get(os.environ.get("MNET_ADAIN_SPLIT", ""))     # A/B knob
 
 
+@_plumbing
 def adain_crop_concat_gn(prior, feat, g_img, g_x1, g_y1, g_w, gamma, beta, eps=1e-6, split=None):
     """adain_crop_concat + the GroupNorm affine of its output (closed form from the AdaIN statistics) → (out, scale, shift).
     ``split``: None = by glyph count; the two forms agree up to the association of the fp64 statistic sums."""
@@ -271,7 +292,7 @@ def adain_crop_concat_gn(prior, feat, g_img, g_x1, g_y1, g_w, gamma, beta, eps=1
     B, FH, FW, FC = feat.shape
     if S != S2 or FH != S or FC != C or prior.dtype != feat.dtype or gamma.numel() != 2 * C:
         raise RuntimeError("adain_crop_concat_gn: shape mismatch prior %s feat %s" % (tuple(prior.shape), tuple(feat.shape)))
-    out = torch.empty((G, S, S, 2 * C), dtype=prior.dtype, device=prior.device)
+    out = new_tensor((G, S, S, 2 * C), prior.dtype, prior.device)
     scale = torch.empty((G, 2 * C), dtype=torch.float32, device=prior.device)
     shift = torch.empty((G, 2 * C), dtype=torch.float32, device=prior.device)
     if split is None:
@@ -290,11 +311,12 @@ def adain_crop_concat_gn(prior, feat, g_img, g_x1, g_y1, g_w, gamma, beta, eps=1
     return out, scale, shift
 
 
+@_plumbing
 def glyph_scatter_affine(feat, scale, shift, g_start, g_x1, g_w):
     lib = _lib.load()
     _need_cuda(feat, scale, shift, g_start, g_x1, g_w)
     B, S, FW, C = feat.shape
-    out = torch.empty_like(feat)
+    out = tag(torch.empty_like(feat))
     _lib.check(lib.mnet_glyph_scatter_affine(_p(feat), _p(scale), _p(shift), _p(out), _dt(feat), B, S, C, FW,
                                              _p(g_start), _p(g_x1), _p(g_w), _stream()), "mnet_glyph_scatter_affine")
     return out
@@ -304,7 +326,7 @@ def layernorm(x, gamma, beta, eps=1e-5):
     lib = _lib.load()
     _need_cuda(x, gamma, beta)
     rows, d = x.shape
-    y = torch.empty_like(x)
+    y = tag(torch.empty_like(x))
     _lib.check(lib.mnet_layernorm(_p(x), _p(gamma), _p(beta), _p(y), rows, d, eps, _stream()), "mnet_layernorm")
     return y
 
@@ -331,17 +353,18 @@ def attention(qkv, B, N, H, scale):
 def pixelnorm(x):
     lib = _lib.load()
     _need_cuda(x)
-    y = torch.empty_like(x)
+    y = tag(torch.empty_like(x))
     _lib.check(lib.mnet_pixelnorm(_p(x), _p(y), x.shape[0], x.shape[1], _stream()), "mnet_pixelnorm")
     return y
 
 
+@_plumbing
 def embed_gather(emb, labels, dtype, num_classes):
     lib = _lib.load()
     _need_cuda(emb, labels)
     N, nc = labels.shape
     C = emb.shape[1]
-    out = torch.empty((N, 4, 4 * nc, C), dtype=dtype, device=emb.device)
+    out = new_tensor((N, 4, 4 * nc, C), dtype, emb.device)
     _lib.check(lib.mnet_embed_gather(_p(emb), _p(labels), _p(out), _dt(out), N, nc, C, num_classes, _stream()),
                "mnet_embed_gather")
     return out
@@ -384,12 +407,13 @@ def argmax_rows(x):
     return idx
 
 
+@_plumbing
 def convert(x, dtype):
     if x.dtype == dtype:
         return x
     lib = _lib.load()
     _need_cuda(x)
-    y = torch.empty(x.shape, dtype=dtype, device=x.device)
+    y = new_tensor(x.shape, dtype, x.device)
     _lib.check(lib.mnet_convert(_p(x), _dt(x), _p(y), _dt(y), x.numel(), _stream()), "mnet_convert")
     return y
 
@@ -404,12 +428,13 @@ def fused_bias_act(x, bias, negative_slope=0.2, scale=2 ** 0.5):
     inner = 1
     for s in x.shape[2:]:
         inner *= s
-    y = torch.empty_like(x)
+    y = tag(torch.empty_like(x))
     _lib.check(lib.mnet_fused_bias_act(_p(x), _p(bias), _p(y), x.numel(), C, inner, negative_slope, scale, _stream()),
                "mnet_fused_bias_act")
     return y
 
 
+@_plumbing
 def sr_postprocess(y_nhwc, u8=True):
     """test_sr.py:198-200 on the NHWC SR tensor [B,H,W,c_ld] (RGB in channels 0..2) → [B,H,W,3] BGR, uint8 (cv2.imwrite's
     rounding) or float32 (the array the script passes to cv2)."""
@@ -422,6 +447,7 @@ def sr_postprocess(y_nhwc, u8=True):
     return out
 
 
+@_plumbing
 def pack_weights(w, dtype, cout_pad=None, cin_pad=None, scale=1.0, sn_u=None, sn_v=None):
     """mnet_pack_weights: w fp32 [cout,cin,kh,kw] (or [out,in] for a Linear) on the device → [cout_pad,kh,kw,cin_pad] in ``dtype``,
     every element (w / sigma) * scale with sigma = uᵀ(W_mat v) when the spectral-norm vectors are given (models/networks.py:14)."""
@@ -438,7 +464,7 @@ def pack_weights(w, dtype, cout_pad=None, cin_pad=None, scale=1.0, sn_u=None, sn
     cout, cin, kh, kw = w.shape
     cout_pad, cin_pad = cout_pad or cout, cin_pad or cin
     rows = mx_weight_rows(cout_pad, kh, kw, cin_pad) if dtype == MX_DTYPE else cout_pad
-    out = (torch.zeros if dtype == MX_DTYPE else torch.empty)((rows, kh, kw, cin_pad), dtype=dtype, device=w.device)
+    out = new_tensor((rows, kh, kw, cin_pad), dtype, w.device, zero=dtype == MX_DTYPE)
     ws = torch.empty((cout + 1,), dtype=torch.float64, device=w.device) if sn_u is not None else None
     _lib.check(lib.mnet_pack_weights(_p(w), cout, cin, kh, kw, _p(sn_u), _p(sn_v), float(scale), _dt(out), cout_pad, cin_pad, _p(out),
                                      _p(ws), _stream()), "mnet_pack_weights")
@@ -471,6 +497,7 @@ def gather_rows(src, col0=0, ncols=None, idx=None):
     return dst
 
 
+@_plumbing
 def conv3x3_rgb(x, wgt, bias, act=ACT_TANH, nhwc=True, nchw=False):
     """conv_final.6 (+ tanh): x NHWC [N,H,W,64]; wgt [3,3,3,64] same dtype (fp32 for a split-half x); bias fp32 [3] → NHWC
     [N,H,W,8] (same dtype; fp32 for a split-half x) and/or fp32 NCHW [N,3,H,W]; returns (y_nhwc or None, y_nchw or None)."""

@@ -26,6 +26,48 @@ PRECISIONS = ("fp32", "fp16", "fp16x3", "fp16x2")
 HALF_PRECISIONS = ("fp16", "fp16x3", "fp16x2")        # modes whose stored values are bounded by the fp16 range
 
 
+_TAG_GUARD = os.environ.get("MARCONET_TAG_GUARD", "1") != "0"
+
+
+class BlockedTensor(torch.Tensor):
+    """A tensor in one of the two 4-byte blocked storages (SPLIT_DTYPE / MX_DTYPE).  The dtype is only a TAG for bytes that this
+    package's kernels interpret (32-channel blocks of halves / fp8 bytes / a scale exponent); any PyTorch arithmetic on them would be
+    silently meaningless (``x + x`` on the complex32 tag adds the hi and lo halves as real and imaginary parts), so everything
+    except storage plumbing — allocation, views, slicing, concatenation over outer dimensions, copies, device moves — raises."""
+
+    _ALLOWED = frozenset((
+        "__get__", "__getitem__", "__len__", "__repr__", "__str__", "__format__", "__deepcopy__", "__reduce_ex__", "__hash__",
+        "view", "reshape", "contiguous", "flatten", "unsqueeze", "squeeze", "narrow", "select", "index_select", "cat", "stack",
+        "chunk", "split", "unbind", "expand", "clone", "detach", "copy_", "to", "cpu", "cuda", "pin_memory", "data_ptr", "numel",
+        "dim", "size", "stride", "element_size", "storage_offset", "untyped_storage", "is_contiguous", "get_device", "equal",
+        "empty_like", "zeros_like", "new_empty", "new_zeros", "zero_", "record_stream", "is_floating_point", "is_complex",
+        "is_pinned", "as_subclass", "_make_subclass", "requires_grad_", "is_shared", "share_memory_", "nbytes", "itemsize",
+        "view_as", "reshape_as", "t_copy", "alias", "is_set_to", "_is_view", "is_same_size", "dim_order"))
+
+    @classmethod
+    def __torch_function__(cls, func, types, args=(), kwargs=None):
+        name = getattr(func, "__name__", None) or str(func)
+        if _TAG_GUARD and name not in cls._ALLOWED:
+            raise TypeError("marconet_amd: %s() on a blocked-storage tensor (%s tag): these bytes are only meaningful to the HIP kernels "
+                            "— convert with ops.convert(t, torch.float32) / packing.to_float(t) first" % (name, "split-half / fp16+8"))
+        return super().__torch_function__(func, types, args, kwargs or {})
+
+
+def tag(t):
+    """mark a tensor of a blocked storage dtype (no copy); other tensors are returned unchanged"""
+    return t.as_subclass(BlockedTensor) if is_split(t.dtype) and type(t) is torch.Tensor else t
+
+
+def untag(t):
+    """the same storage as a plain torch.Tensor (host-side packers / debugging helpers that do arithmetic on the raw halves)"""
+    return t.as_subclass(torch.Tensor) if isinstance(t, BlockedTensor) else t
+
+
+def new_tensor(shape, dtype, device, zero=False):
+    """allocation of an activation / weight buffer in any storage dtype (blocked dtypes come back tagged)"""
+    return tag((torch.zeros if zero else torch.empty)(tuple(shape), dtype=dtype, device=device))
+
+
 def is_split(dtype):
     """the two 4-byte blocked storages (split half / fp16+8): 32-channel blocks, 128-byte aligned"""
     return dtype == SPLIT_DTYPE or dtype == MX_DTYPE
@@ -67,11 +109,12 @@ def split_halves(t):
     lo = (t - hi.float()).to(torch.float16)
     blk = t.shape[:-1] + (t.shape[-1] // 32, 32)
     both = torch.stack((hi.reshape(blk), lo.reshape(blk)), dim=-2).contiguous()          # [..., C/32, 2, 32] halves
-    return both.view(SPLIT_DTYPE).reshape(t.shape)
+    return tag(both.view(SPLIT_DTYPE).reshape(t.shape))
 
 
 def to_float(t):
     """any storage dtype → fp32 (tests / debugging; host or device tensor)"""
+    t = untag(t)
     if t.dtype == SPLIT_DTYPE:
         return unsplit_halves(t)
     if t.dtype == MX_DTYPE:
@@ -86,12 +129,13 @@ def from_float(t, dtype):
         return split_halves(t)
     if dtype == MX_DTYPE:
         from . import mxfmt
-        return mxfmt.pack_act(t).view(MX_DTYPE)
+        return tag(mxfmt.pack_act(t).view(MX_DTYPE))
     return t.to(dtype)
 
 
 def unsplit_halves(t):
     """inverse of split_halves (tests / debugging): split-half tensor → fp32"""
+    t = untag(t)
     c = t.shape[-1]
     h = t.contiguous().view(torch.float16).reshape(t.shape[:-1] + (c // 32, 2, 32)).float()
     return (h[..., 0, :] + h[..., 1, :]).reshape(t.shape)
@@ -149,7 +193,7 @@ def mx_weight_tensor(flat_u8, cout_pad, kh, kw, cin_pad):
     rows = mx_weight_rows(cout_pad, kh, kw, cin_pad)
     buf = torch.zeros((rows * kh * kw * cin_pad * 4,), dtype=torch.uint8, device=flat_u8.device)
     buf[: flat_u8.numel()] = flat_u8
-    return buf.view(MX_DTYPE).reshape(rows, kh, kw, cin_pad)
+    return tag(buf.view(MX_DTYPE).reshape(rows, kh, kw, cin_pad))
 
 
 def pack_linear_weight(w, scale=1.0):
@@ -264,7 +308,7 @@ def _flatten(obj, path, tensors, tree):
     if torch.is_tensor(obj):
         split = is_split(obj.dtype)               # safetensors has no such dtype: stored as the raw halves, re-tagged on load
         tree[path] = {"t": "tensor", "split": split, "mx": obj.dtype == MX_DTYPE}
-        t = obj.detach().contiguous().cpu()
+        t = untag(obj.detach()).contiguous().cpu()
         tensors[path] = (t.view(torch.float16) if split else t).clone()
     elif isinstance(obj, dict):
         if not all(isinstance(k, str) and "/" not in k for k in obj):
@@ -286,7 +330,7 @@ def _unflatten(path, get_tensor, tree):
     node = tree[path]
     if node["t"] == "tensor":
         t = get_tensor(path)
-        return t.view(MX_DTYPE if node.get("mx") else SPLIT_DTYPE) if node.get("split") else t
+        return tag(t.view(MX_DTYPE if node.get("mx") else SPLIT_DTYPE)) if node.get("split") else t
     if node["t"] == "dict":
         return {k: _unflatten(path + "/" + k, get_tensor, tree) for k in node["keys"]}
     if node["t"] in ("tuple", "list"):

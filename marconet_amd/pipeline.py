@@ -12,7 +12,7 @@ import torch
 
 from . import ops
 from .glyphs import GlyphTables
-from .packing import default_precision, torch_dtype
+from .packing import default_precision, new_tensor, torch_dtype
 
 
 import os as _os
@@ -91,8 +91,8 @@ class MarconetPipeline:
             # the generator runs in chunks of glyphs (bounded working set for huge batches) and writes its two prior levels
             # straight into the all-glyph buffers TSPSRNet reads (no concatenation pass: 34 GB of copies per step at batch 256)
             G, gdt = lab.shape[0], torch_dtype(tg.precision)
-            p64 = torch.empty((G, 64, 64, 256), dtype=gdt, device=lq.device)
-            p32 = torch.empty((G, 32, 32, 512), dtype=gdt, device=lq.device)
+            p64 = new_tensor((G, 64, 64, 256), gdt, lq.device)
+            p32 = new_tensor((G, 32, 32, 512), gdt, lq.device)
             for s in range(0, G, self.glyph_chunk):
                 e = min(G, s + self.glyph_chunk)
                 if _NO_STYLE_DEDUPE:

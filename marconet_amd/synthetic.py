@@ -68,17 +68,25 @@ def _t(a):
 _RESNET_LAYERS = [(32, 3), (64, 4), (128, 6), (256, 6), (512, 3)]   # models/resnet.py:74 [3,4,6,6,3]
 
 
-def make_encoder_state_dict(seed=1234):
-    """Keys of ``TextContextEncoderV2`` (models/networks.py:27-45)."""
+def make_encoder_state_dict(seed=1234, resnet_gain=None, input_gain=1.0, cls_gain=3.0):
+    """Keys of ``TextContextEncoderV2`` (models/networks.py:27-45).
+    Stress variants (tests/test_stress_gpu.py): ``resnet_gain=1.0`` = the reference's own initialisation of every ResNet conv
+    (models/resnet.py:45-48: features of std ~78, |max| ~610); ``input_gain`` multiplies conv1 — the BN-free,
+    bias-free ReLU stack is positively homogeneous, so it scales every ResNet activation by that factor; ``cls_gain=1.0`` leaves
+    near-ties among the 6736 logits (top-2 gaps down to 1e-4 and below)."""
     sd = {}
 
     def conv_w(key, cout, cin, k, gain):
         # reference init is N(0, sqrt(2/(k*k*cout))) (models/resnet.py:45-48); gain<1 keeps the
         # BN-free 45-layer stack from growing to |x|~600
+        if resnet_gain is not None:
+            gain = resnet_gain
         std = gain * math.sqrt(2.0 / (k * k * cout))
         sd[key] = _t(normal(seed, key, (cout, cin, k, k)) * std)
 
     conv_w("resnet.conv1.weight", 32, 3, 3, 1.0)
+    if input_gain != 1.0:
+        sd["resnet.conv1.weight"] = sd["resnet.conv1.weight"] * float(input_gain)
     inpl = 32
     for li, (planes, nblk) in enumerate(_RESNET_LAYERS, 1):
         for bi in range(nblk):
@@ -113,7 +121,7 @@ def make_encoder_state_dict(seed=1234):
     layernorm("transformer.transformer.linear_seq_maxlen.0", 64)
     linear("transformer.transformer.linear_seq_maxlen.1", 16, 64)
     layernorm("transformer.linear_cls.0", 512)
-    linear("transformer.linear_cls.1", NUM_CLASSES, 512, gain=3.0)   # wider top-2 logit gaps
+    linear("transformer.linear_cls.1", NUM_CLASSES, 512, gain=cls_gain)   # 3.0: wider top-2 logit gaps
     layernorm("transformer.linear_locs.0", 512)
     linear("transformer.linear_locs.1", 256, 512)
     linear("transformer.linear_locs.3", 2, 256)

@@ -190,3 +190,99 @@ def test_forced_collective_in_a_world_of_one_gloo():
     res = q.get(timeout=120)
     p.join(timeout=60)
     assert res == (True, True, True)
+
+
+# ------------------------------------------------------------------------------------------------ configs[4] on 8 ranks
+class _MixedStandIn:
+    """MarconetPipeline._forward_mixed_widths over stand-in nets (CPU): every image's output is a deterministic function of that
+    image's strip, bucket width, labels, priors and glyph windows only — what the real nets guarantee (batch-invariant kernels)"""
+
+    class _Enc(torch.nn.Module):
+        def forward(self, lq):
+            w = lq.mean(dim=(1, 2, 3)).reshape(-1, 1).expand(-1, 512).contiguous()
+            return None, None, w
+
+    class _TG:
+        precision, class_num = "fp32", 6736
+
+        def forward_nhwc(self, styles, labels, need_image=True, style_index=None, p64_out=None, p32_out=None):
+            v = styles[:, :1] + labels.float() * 1e-3
+            return None, v.reshape(-1, 1, 1, 1).expand(-1, 2, 2, 4).contiguous(), (2 * v).reshape(-1, 1, 1, 1).expand(-1, 1, 1, 4).contiguous()
+
+    class _SR(torch.nn.Module):
+        precision = "fp32"
+
+        def forward_packed(self, lq, p64, p32, c64, c32, locs, nchw_out=False, tables=None):
+            out, g0 = [], 0
+            for b, c in enumerate(c64):
+                v = lq[b].sum() + float(lq.shape[3])
+                if c:
+                    t64, t32 = tables[1], tables[0]
+                    v = v + p64[g0:g0 + c].sum() + p32[g0:g0 + c].sum() + float(t64.g_x1[g0:g0 + c].sum() + t32.g_w[g0:g0 + c].sum())
+                g0 += c
+                out.append(v.reshape(1, 1, 1).expand(3, 128, 4 * lq.shape[3]))
+            return torch.stack(out).contiguous()
+
+    def __init__(self):
+        from marconet_amd.pipeline import MarconetPipeline
+        self.encoder, self.sr = self._Enc(), self._SR()
+        self.gan = type("G", (), {"TextGenerator": self._TG()})()
+        self.precision, self.need_prior_image, self.check_finite, self._finite = "fp32", True, False, None
+        self._checks = lambda: False
+        self._raise_if_not_finite = lambda: None
+        self.run = MarconetPipeline._forward_mixed_widths.__get__(self)
+
+
+def _mixed_problem(total):
+    import random
+    rng = random.Random(11)
+    widths = [rng.choice([128, 192, 256, 320, 384, 448, 512]) - rng.randint(0, 30) for _ in range(total)]
+    counts = [min(16, max(0, w // 32 - rng.randint(0, 3))) for w in widths]
+    g = torch.Generator().manual_seed(12)
+    lq = torch.rand((total, 3, 32, 512), generator=g)
+    labels = [torch.randint(0, 6000, (c, 1), generator=g) for c in counts]
+    locs = torch.zeros((total, 32))
+    for b, (w, c) in enumerate(zip(widths, counts)):
+        for j in range(c):
+            locs[b, 2 * j] = (j + 0.5) * (w / max(c, 1)) / 512.0
+            locs[b, 2 * j + 1] = 0.4 * (w / max(c, 1)) / 512.0
+    return lq, widths, counts, labels, locs
+
+
+def _mixed_worker(rank, world, port, total, out_q):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from marconet_amd.pipeline import balance_shards
+        lq, widths, counts, labels, locs = _mixed_problem(total)
+        mine = balance_shards(widths, counts, world)[rank]
+        pipe = _MixedStandIn()
+        outs = pipe.run(lq[mine], [widths[i] for i in mine], [labels[i] for i in mine], locs[mine], 64) if mine else []
+        local = [(i, tuple(o.shape), float(o.double().sum())) for i, o in zip(mine, outs)]
+        gathered = [None] * world
+        dist.all_gather_object(gathered, local)
+        if rank == 0:
+            whole = pipe.run(lq, widths, labels, locs, 64)
+            want = {i: (tuple(o.shape), float(o.double().sum())) for i, o in enumerate(whole)}
+            got = {i: (s, v) for part in gathered for i, s, v in part}
+            out_q.put((sorted(got) == list(range(total)), all(got[i] == want[i] for i in range(total)), [len(p_) for p_ in gathered]))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_config5_mixed_widths_on_8_simulated_ranks():
+    """BASELINE configs[4] (mixed widths, length bucketing, 8 GPUs) with the hardware replaced by 8 gloo ranks and stand-in nets:
+    balance_shards + forward_mixed_widths per rank reproduce the single-rank outputs image for image (test_sr.py:105-110)"""
+    world, total = 8, 61
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_mixed_worker, args=(r, world, port, total, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    covered, equal, sizes = q.get(timeout=300)
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    assert covered and equal and sum(sizes) == total and max(sizes) - min(sizes) <= 3

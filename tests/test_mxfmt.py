@@ -73,3 +73,25 @@ def test_decomposition_accuracy():
     e_mx = (y.double() - ref).abs().max().item() / ref.abs().max().item()
     e_16 = (F.conv2d(x.half().float(), w.half().float(), padding=1).double() - ref).abs().max().item() / ref.abs().max().item()
     assert e_mx < 3e-5 and e_16 > 8 * e_mx
+
+
+def test_blocked_storage_tensors_refuse_arithmetic():
+    """the 4-byte tags (complex32 / uint32) only carry bytes for the HIP kernels — any torch arithmetic on them raises,
+    storage plumbing (views, slices, cat over outer dimensions, clone, device moves) keeps working and keeps the tag"""
+    import pytest
+    x = _rnd((2, 3, 4, 64), 9)
+    for dt in (packing.SPLIT_DTYPE, packing.MX_DTYPE):
+        s = packing.from_float(x, dt)
+        assert isinstance(s, packing.BlockedTensor) and s.dtype == dt and s.shape == x.shape
+        for bad in (lambda: s + s, lambda: s * 2.0, lambda: s.sum(), lambda: s.float(), lambda: torch.isfinite(s), lambda: torch.add(s, 1), lambda: s.abs()):
+            with pytest.raises(TypeError):
+                bad()
+        part = s[1:]
+        assert isinstance(part, packing.BlockedTensor) and isinstance(s.clone(), packing.BlockedTensor) and isinstance(s.contiguous(), packing.BlockedTensor)
+        assert part.data_ptr() == s.data_ptr() + 3 * 4 * 64 * 4 and s.is_contiguous() and s.numel() == x.numel() and s.element_size() == 4
+        assert torch.equal(packing.to_float(part), packing.to_float(s)[1:])
+        from marconet_amd import ops
+        both = ops.cat_rows([s, s])
+        assert isinstance(both, packing.BlockedTensor) and both.shape == (4, 3, 4, 64) and torch.equal(packing.to_float(both)[2:], packing.to_float(s))
+        sel = ops.take_rows(s, torch.tensor([1, 0]))
+        assert isinstance(sel, packing.BlockedTensor) and torch.equal(packing.to_float(sel)[0], packing.to_float(s)[1])
