@@ -38,7 +38,16 @@ template <typename To, typename From>
 __device__ __forceinline__ To bitcast(const From& v) { return __builtin_bit_cast(To, v); }
 
 __device__ __forceinline__ u32x4 ldg16(const void* p) { return *reinterpret_cast<const u32x4*>(p); }
-__device__ __forceinline__ void stg16(void* p, u32x4 v) { *reinterpret_cast<u32x4*>(p) = v; }
+#ifndef MNET_NT_STORE
+#define MNET_NT_STORE 0      // 1: 16-byte stores of the streaming kernels bypass L2 allocation (A/B build: EXTRA_HIPCC_FLAGS=-DMNET_NT_STORE=1)
+#endif
+__device__ __forceinline__ void stg16(void* p, u32x4 v) {
+#if MNET_NT_STORE
+    __builtin_nontemporal_store(v, reinterpret_cast<u32x4*>(p));
+#else
+    *reinterpret_cast<u32x4*>(p) = v;
+#endif
+}
 
 // number of elements in a 16-byte chunk
 template <typename T> struct ChunkOf { static constexpr int N = 16 / sizeof(T); };

@@ -687,11 +687,12 @@ int conv_dma_pick(const ConvArgs& a) {
     // first group's MFMAs): 472 vs 465 TFLOP/s (+1.5 %); the 128x512 tile does not gain (id 12 stays an A/B knob)
     static const int env_x3_256 = [] { const char* e = getenv("MNET_X3_CFG256"); return e ? atoi(e) : 11; }();
     if (a.split == 2) {
-        static const int env_mx_256 = [] { const char* e = getenv("MNET_MX_CFG256"); return e ? atoi(e) : 6; }();      // A/B knobs
+        static const int env_mx_256 = [] { const char* e = getenv("MNET_MX_CFG256"); return e ? atoi(e) : 11; }();     // A/B knobs (id 11 = id 6 with the LDS reads placed by scheduling hints: 538 vs 530 TFLOP/s)
         static const int env_mx_128 = [] { const char* e = getenv("MNET_MX_CFG128"); return e ? atoi(e) : 8; }();
         if (a.cout >= 256) return big ? env_mx_256 : (t128 * ((a.cout + 255) / 256) < 200 ? 10 : 1);
         if (a.cout >= 128) return big ? env_mx_128 : (t256 * ((a.cout + 127) / 128) < 200 ? 10 : 2);
-        return big ? 5 : 3;
+        static const int env_mx_64 = [] { const char* e = getenv("MNET_MX_CFG64"); return e ? atoi(e) : 13; }();       // id 13 = id 5 + hints: 260 vs 251
+        return big ? env_mx_64 : 3;
     }
     if (a.split && big && a.cout >= 128) return env_x3_16w ? (a.cout >= 256 ? 0 : 4) : (a.cout >= 256 ? env_x3_256 : env_x3_128);
     // f16 big tiles: ids 8 / 9 = ids 0 / 4 with the next slab's DMA pieces issued between the two half slabs instead of right after
