@@ -125,7 +125,12 @@ int mnet_conv2d_nhwc(const mnet_conv_desc* d, void* stream);
  *   MNET_F16X2 launches: ids 0-6 and 10 as above on the split-half form, id 7 = 128x512 8w (64x128 per wave), ids 8 / 9 = ids 6 / 7
  *      with the DMA pieces issued after the first multiply group, ids 11 / 12 = ids 8 / 9 with the LDS reads placed by scheduling
  *      hints; AUTO takes the 8-wave tiles 11 (cout >= 256) / 9 (cout 128) for >= 65536 output pixels
- *   id 11-15: diagnostic builds used by tools/wg_timeline.py and tools/conv_bench.py; they produce WRONG results */
+ *   MNET_F16M launches: ids 0-5, 10 = the same tile shapes on v_mfma_f32_32x32x16_f16 + v_mfma_scale_f32_32x32x64_f8f6f4, id 6 = 256x256
+ *      8w (128x64 per wave), id 7 / 8 = 128x512 8w (64x128 / 128x64 per wave), ids 11 / 12 / 13 = ids 6 / 8 / 5 with the LDS reads
+ *      placed by scheduling hints; AUTO takes 11 (cout >= 256) / 8 (cout 128) / 13 (cout 64) for >= 65536 output pixels; every id
+ *      runs the same MFMA sequence per output (same bytes whatever the launch size selects)
+ *   MNET_F16 ids 11-15 ONLY: diagnostic builds used by tools/wg_timeline.py and tools/conv_bench.py; they produce WRONG results and
+ *      are refused (MNET_E_ARG) unless the process sets MNET_ALLOW_DIAGNOSTIC_KERNELS=1 */
 enum { MNET_CONV_ALGO_AUTO = 0, MNET_CONV_ALGO_REG_STAGED = 1, MNET_CONV_ALGO_LDS_DMA = 2,
        MNET_CONV_ALGO_SKINNY = 3 /* fp32 1x1 over <= 512 pixels straight from global memory (the TextViT linears of a small batch;
                                   * 16 x 64 tiles).  AUTO uses it when eligible; bit-identical to REG_STAGED. */,
@@ -283,6 +288,14 @@ int mnet_convert(const void* src, int32_t src_dtype, void* dst, int32_t dst_dtyp
  * fused into mnet_conv2d_nhwc's epilogue.) */
 int mnet_fused_bias_act(const float* x, const float* bias, float* y, int64_t total, int32_t C, int32_t inner,
                         float negative_slope, float scale, void* stream);
+
+/* ToRGB.forward (models/networks.py:313-321; call sites :148,157): modulated 1x1 conv to RGB without demodulation + bias + the
+ * bilinearly up-sampled (x2, align_corners=False) RGB image of the level below, then tanh — one streaming pass over x.
+ *   out[n,y,x,o] = tanh( scale_b[n] * sum_c wgt[o][c] * (x[n,y,x,c] * style[n][c]) + bias[o] + up2(skip)[n,y,x,o] ),  out[..,3] = 0
+ * x NHWC [n,h,w,c] in any storage dtype (c in {64,128,256,512}); wgt fp32 [3][c] (the layer's constant scale folded); style fp32 [n][c];
+ * scale_b fp32 [n] or NULL (1); bias fp32 [3]; skip fp32 [n,h/2,w/2,4] or NULL; out fp32 [n,h,w,4]. */
+int mnet_torgb(const void* x, int32_t dtype, int32_t n, int32_t h, int32_t w, int32_t c, const float* wgt, const float* style,
+               const float* scale_b, const float* bias, const float* skip, float* out, void* stream);
 
 /* 3x3 / stride 1 / pad 1 convolution of a cin = 64 map to 3 output channels + bias (+ tanh): the last layer of TSPSRNet
  * (conv_final.6 + Tanh, models/networks.py:374-375).  x NHWC [n,h,w,64] (f16 or f32); wgt [3][3][3][64] (cout, kh, kw, cin) in

@@ -73,6 +73,7 @@ SYMBOLS = {
     "mnet_argmax_rows": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p]),
     "mnet_convert": (c_int, [c_void_p, c_int, c_void_p, c_int, c_i64, c_void_p]),
     "mnet_fused_bias_act": (c_int, [c_void_p, c_void_p, c_void_p, c_i64, c_int, c_int, c_float, c_float, c_void_p]),
+    "mnet_torgb": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "mnet_conv3x3_rgb": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p]),
     "mnet_sr_postprocess": (c_int, [c_void_p, c_int, c_void_p, c_int, c_i64, c_int, c_void_p]),
     "mnet_pack_weights": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_float, c_int, c_int, c_int, c_void_p,

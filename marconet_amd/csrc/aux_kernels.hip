@@ -930,6 +930,74 @@ extern "C" int mnet_sr_postprocess(const void* src, int32_t src_dtype, void* dst
     return MNET_OK;
 }
 
+// ============================================================================ ToRGB (StyleGAN skip branch)
+// ToRGB.forward (models/networks.py:313-321): a MODULATED 1x1 conv to 3 channels without demodulation, + bias, + the bilinearly
+// up-sampled RGB of the level below, then tanh.  Through the implicit-GEMM kernel this is a register-staged launch with a style
+// prologue that wastes a 32-wide MFMA tile on 3 outputs (2.8 TB/s split-half, 1.5 TB/s fp16+8: 52 ms per step) plus an up-sample
+// pass over a 32-channel-padded RGB tensor.  Here: one streaming pass over x — a thread takes 8 channels of a pixel, multiplies
+// them by the style and the three weight rows, the C/8 lanes of the pixel fold their partial sums by butterfly shuffles, lane 0
+// adds bias and the up-sampled skip (4 taps of the fp32 [N,H/2,W/2,4] image below, horizontal first like ATen) and writes fp32 RGB0.
+//   out[n,y,x,o] = tanh( sb[n] * sum_c W[o,c] * (x[n,y,x,c] * s[n,c]) + bias[o] + up2(skip)[n,y,x,o] )
+template <typename T>
+__global__ void __launch_bounds__(256) torgb_kernel(const T* __restrict__ x, const float* __restrict__ wgt, const float* __restrict__ style,
+                                                    const float* __restrict__ sb, const float* __restrict__ bias,
+                                                    const float* __restrict__ skip, float* __restrict__ out, int H, int W, int C) {
+    const int cpp = C >> 3;                                    // lanes per pixel (16, 32 or 64: a power of two <= 64)
+    const int t = threadIdx.x, ch = t & (cpp - 1), pl = t / cpp, ppb = 256 / cpp;
+    const int n = blockIdx.y, HW = H * W;
+    float s8[8], w0[8], w1[8], w2[8];
+    {
+        const float* sp = style + (size_t)n * C + ch * 8;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { s8[j] = sp[j]; w0[j] = wgt[ch * 8 + j]; w1[j] = wgt[C + ch * 8 + j]; w2[j] = wgt[2 * C + ch * 8 + j]; }
+    }
+    const float osc = sb ? sb[n] : 1.f;
+    const T* xb = x + (size_t)n * HW * C + (size_t)ch * 8;
+    const int h2 = H >> 1, w2_ = W >> 1;
+    const float* kb = skip ? skip + (size_t)n * h2 * w2_ * 4 : nullptr;
+    for (int pix = blockIdx.x * ppb + pl; pix < HW; pix += gridDim.x * ppb) {
+        float v[8];
+        ld8<T>(xb + (size_t)pix * C, v);
+        float p0 = 0.f, p1 = 0.f, p2 = 0.f;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { const float m = v[j] * s8[j]; p0 = fmaf(m, w0[j], p0); p1 = fmaf(m, w1[j], p1); p2 = fmaf(m, w2[j], p2); }
+        for (int o = 1; o < cpp; o <<= 1) { p0 += __shfl_xor(p0, o, 64); p1 += __shfl_xor(p1, o, 64); p2 += __shfl_xor(p2, o, 64); }
+        if (ch != 0) continue;
+        float r0 = p0 * osc + bias[0], r1 = p1 * osc + bias[1], r2 = p2 * osc + bias[2];
+        if (kb) {
+            const int y = pix / W, xx = pix - y * W;
+            const int jy = y >> 1, jx = xx >> 1;
+            const int ya = (y & 1) ? jy : max(jy - 1, 0), yb = (y & 1) ? min(jy + 1, h2 - 1) : jy;
+            const int xa = (xx & 1) ? jx : max(jx - 1, 0), xb2 = (xx & 1) ? min(jx + 1, w2_ - 1) : jx;
+            const float wya = (y & 1) ? 0.75f : 0.25f, wxa = (xx & 1) ? 0.75f : 0.25f;
+            const f32x4 aa = *reinterpret_cast<const f32x4*>(kb + ((size_t)ya * w2_ + xa) * 4), ab = *reinterpret_cast<const f32x4*>(kb + ((size_t)ya * w2_ + xb2) * 4);
+            const f32x4 ba = *reinterpret_cast<const f32x4*>(kb + ((size_t)yb * w2_ + xa) * 4), bb = *reinterpret_cast<const f32x4*>(kb + ((size_t)yb * w2_ + xb2) * 4);
+            const f32x4 top = aa * wxa + ab * (1.f - wxa), bot = ba * wxa + bb * (1.f - wxa);
+            const f32x4 up = top * wya + bot * (1.f - wya);
+            r0 += up[0]; r1 += up[1]; r2 += up[2];
+        }
+        *reinterpret_cast<f32x4*>(out + ((size_t)n * HW + pix) * 4) = f32x4{tanhf(r0 - r0 + r0), tanhf(r1 - r1 + r1), tanhf(r2 - r2 + r2), 0.f};
+    }
+}
+
+extern "C" int mnet_torgb(const void* x, int32_t dtype, int32_t n, int32_t h, int32_t w, int32_t c, const float* wgt, const float* style,
+                          const float* scale_b, const float* bias, const float* skip, float* out, void* stream) {
+    MNET_CHECK_ARG(x && wgt && style && bias && out && n > 0 && h > 0 && w > 0 && n <= 65535, "torgb: bad args");
+    MNET_CHECK_ARG(dtype == MNET_F32 || dtype == MNET_F16 || is_split4(dtype), "torgb: bad dtype");
+    MNET_CHECK_ARG(c >= 64 && c <= 512 && (c & (c - 1)) == 0, "torgb: c=%d (supported: 64, 128, 256, 512)", c);
+    MNET_CHECK_ARG(!skip || (h % 2 == 0 && w % 2 == 0), "torgb: a skip image needs even h, w");
+    MNET_CHECK_ALIGN(aligned16(x) && aligned16(skip) && aligned16(out) && (!is_split4(dtype) || aligned128(x)), "torgb: unaligned pointer");
+    const long long groups = ((long long)h * w + (256 / (c / 8)) - 1) / (256 / (c / 8));
+    const int gx = (int)(groups < 4096 ? groups : 4096);
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    if (dtype == MNET_F16) hipLaunchKernelGGL(torgb_kernel<f16>, dim3(gx, n), dim3(256), 0, st, (const f16*)x, wgt, style, scale_b, bias, skip, out, h, w, c);
+    else if (dtype == MNET_F16X2) hipLaunchKernelGGL(torgb_kernel<hs>, dim3(gx, n), dim3(256), 0, st, (const hs*)x, wgt, style, scale_b, bias, skip, out, h, w, c);
+    else if (dtype == MNET_F16M) hipLaunchKernelGGL(torgb_kernel<hm>, dim3(gx, n), dim3(256), 0, st, (const hm*)x, wgt, style, scale_b, bias, skip, out, h, w, c);
+    else hipLaunchKernelGGL(torgb_kernel<float>, dim3(gx, n), dim3(256), 0, st, (const float*)x, wgt, style, scale_b, bias, skip, out, h, w, c);
+    MNET_LAUNCH_CHECK("torgb");
+    return MNET_OK;
+}
+
 // ============================================================================ 3x3 conv to RGB (the last layer of TSPSRNet)
 // conv_final.6 + tanh (models/networks.py:374-375): 64 → 3 channels at 128 x 2048.  Through the implicit-GEMM kernel this
 // wastes a 16-wide MFMA tile on 3 outputs (1.84 ms per 64 images, 1.1 TB/s) and needs a separate NHWC→NCHW pass for the

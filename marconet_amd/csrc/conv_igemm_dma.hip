@@ -658,6 +658,17 @@ static int launch_dma_id(int id, const ConvArgs& a, hipStream_t st) {
                                                                                             // DMA pieces between the halves: AUTO for cout >= 256
         case 17: return launch_dma_cfg<128, 512, 2, 4, 2, 16, 0, false, true, true>(a, st);   // the same form of the 128x512 tile (64x128 per wave)
         case 10: return launch_dma_cfg<128, 128, 2, 4, 4>(a, st);          // small launches: twice the workgroups of ids 1 / 2, 3 slabs in flight
+        case 11: case 12: case 13: case 14: case 15: {
+            // MNET_F16 ids 11-15 are DIAGNOSTIC builds that produce WRONG results on purpose (tools/wg_timeline.py, tools/conv_bench.py):
+            // refused unless the process opts in, so that a C-ABI host cannot select one by accident (the same ids are production
+            // tiles for MNET_F16X2 / MNET_F16M launches, which never reach this table)
+            static const bool allow = [] { const char* e = getenv("MNET_ALLOW_DIAGNOSTIC_KERNELS"); return e && atoi(e) != 0; }();
+            if (!allow) return mnet_fail(MNET_E_ARG, "conv: MNET_F16 LDS-DMA id %d is a diagnostic build with wrong results (set MNET_ALLOW_DIAGNOSTIC_KERNELS=1 to use it)", id);
+            break;
+        }
+        default: break;
+    }
+    switch (id) {
         case 11: return launch_dma_cfg<256, 256, 4, 4, 2, 16, 4>(a, st);  // DIAGNOSTIC: all tiles store over tile 0; stamps after tile 0
         case 12: return launch_dma_cfg<256, 256, 4, 4, 2, 16, 5>(a, st);  // DIAGNOSTIC: no output stores; stamps after tile 0
         case 13: return launch_dma_cfg<256, 256, 4, 4, 2, 16, 3>(a, st);  // DIAGNOSTIC: per-tile time stamps written over the output

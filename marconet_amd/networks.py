@@ -191,10 +191,11 @@ class TextGenerator(nn.Module):
 
         def torgb(tr):
             mc = tr.conv
-            return dict(cin=mc.in_channel, cout=rgb_pad(dtype),
-                        w=pack_conv_weight(mc.weight.detach()[0], dtype, cout_mult=rgb_pad(dtype), scale=mc.scale),   # [3,Cin,1,1]
+            # [3,Cin,1,1] → fp32 [3,Cin] with the layer's constant scale folded: the dedicated ToRGB kernel (mnet_torgb) does its three
+            # dot products per pixel in fp32 in every precision mode
+            return dict(cin=mc.in_channel, w=pack_conv_weight(mc.weight.detach()[0], torch.float32, cin_mult=1, cout_mult=1, scale=mc.scale).reshape(3, -1).contiguous(),
                         mod_w=pack_linear_weight(mc.modulation.weight, mc.modulation.scale), mod_b=f(mc.modulation.bias),
-                        bias=pack_vec(tr.bias, rgb_pad(dtype)))
+                        bias=pack_vec(tr.bias, 4))
 
         pk["conv1"] = styled(self.conv1)
         pk["rgb1"] = torgb(self.to_rgb1)
@@ -240,13 +241,12 @@ class TextGenerator(nn.Module):
                           out_scale=d, bias=L["bias"], act=ops.ACT_LRELU_SQRT2, post_scale=post, out=out)
 
     def _to_rgb(self, L, x, skip):
-        s, _, sb = self._mod(L, self._gidx, bcast=L["cout"])
-        if skip is not None:
-            skip = ops.upsample2x(skip)                                        # :318-319
-        return ops.conv2d(x, L["w"], L["cout"], in_scale=s, out_scale=sb, bias=L["bias"], residual=skip, act=ops.ACT_TANH)
+        """ToRGB.forward (:313-321) as ONE streaming kernel: modulated 1x1 conv + bias + up-sampled skip (:318-319) + tanh → fp32 RGB0"""
+        s, _, sb = self._mod(L, self._gidx, bcast=1)
+        return ops.torgb(x, L["w"], s, sb, L["bias"], skip)
 
     def forward_nhwc(self, styles, labels, need_image=True, style_index=None, p64_out=None, p32_out=None):
-        """→ (image NHWC [N,128,128c,8], prior64 NHWC [N,64,64c,256], prior32 NHWC [N,32,32c,512]).
+        """→ (image NHWC fp32 [N,128,128c,4] (RGB0), prior64 NHWC [N,64,64c,256], prior32 NHWC [N,32,32c,512]).
         ``style_index`` (int64 [N], optional): ``styles`` then holds only the DISTINCT style vectors (one per image in
         test_sr.py:183, where every glyph of an image gets the same w) and glyph i uses styles[style_index[i]] — the style
         MLP, the 17 modulations and the 11 demodulation tables run once per distinct style and are gathered per glyph.

@@ -17,7 +17,7 @@ from .packing import MX_DTYPE, SPLIT_DTYPE, is_split, mx_weight_rows, new_tensor
 
 __all__ = ["conv2d", "linear", "nchw_to_nhwc", "nhwc_to_nchw", "upsample2x", "affine_act", "groupnorm_affine",
            "adain_crop_concat", "adain_crop_concat_gn", "glyph_scatter_affine", "layernorm", "token_mix", "attention", "pixelnorm",
-           "embed_gather", "demod", "argmax_rows", "convert", "fused_bias_act", "sr_postprocess", "conv3x3_rgb", "stats",
+           "embed_gather", "demod", "argmax_rows", "convert", "fused_bias_act", "sr_postprocess", "conv3x3_rgb", "torgb", "stats",
            "pack_weights", "pack_wsq", "gather_rows", "style_rows",
            "ACT_NONE", "ACT_RELU", "ACT_LRELU", "ACT_LRELU_SQRT2", "ACT_TANH", "ACT_GELU", "ACT_SIGMOID"]
 
@@ -495,6 +495,22 @@ def gather_rows(src, col0=0, ncols=None, idx=None):
     if rows:
         _lib.check(lib.mnet_gather_rows(_p(src), src.shape[0], ld, col0, ncols, _p(idx), rows, _p(dst), _stream()), "mnet_gather_rows")
     return dst
+
+
+@_plumbing
+def torgb(x, wgt, style, scale_b, bias, skip=None):
+    """mnet_torgb (ToRGB.forward, models/networks.py:313-321): x NHWC [N,H,W,C] any storage dtype; wgt fp32 [3,C]; style fp32 [N,C];
+    scale_b fp32 [N] / [N,1] or None; bias fp32 [>=3]; skip fp32 [N,H/2,W/2,4] or None → fp32 [N,H,W,4] (RGB0)"""
+    lib = _lib.load()
+    _need_cuda(x, wgt, style, scale_b, bias, skip)
+    n, h, w, c = x.shape
+    if wgt.dtype != torch.float32 or wgt.numel() != 3 * c or style.dtype != torch.float32 or tuple(style.shape) != (n, c):
+        raise RuntimeError("torgb: weight [3,C] / style [N,C] fp32 expected")
+    if skip is not None and (skip.dtype != torch.float32 or tuple(skip.shape) != (n, h // 2, w // 2, 4)):
+        raise RuntimeError("torgb: skip must be fp32 [N,H/2,W/2,4]")
+    out = torch.empty((n, h, w, 4), dtype=torch.float32, device=x.device)
+    _lib.check(lib.mnet_torgb(_p(x), _dt(x), n, h, w, c, _p(wgt), _p(style), _p(scale_b), _p(bias), _p(skip), _p(out), _stream()), "mnet_torgb")
+    return out
 
 
 @_plumbing

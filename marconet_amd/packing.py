@@ -50,7 +50,14 @@ class BlockedTensor(torch.Tensor):
         if _TAG_GUARD and name not in cls._ALLOWED:
             raise TypeError("marconet_amd: %s() on a blocked-storage tensor (%s tag): these bytes are only meaningful to the HIP kernels "
                             "— convert with ops.convert(t, torch.float32) / packing.to_float(t) first" % (name, "split-half / fp16+8"))
-        return super().__torch_function__(func, types, args, kwargs or {})
+        out = super().__torch_function__(func, types, args, kwargs or {})
+        # a view under another dtype (``t.view(torch.uint8)``, ``.view(torch.float16)``: raw bytes / halves for the host-side packers)
+        # is an ordinary tensor again
+        if isinstance(out, BlockedTensor):
+            return out if is_split(out.dtype) else out.as_subclass(torch.Tensor)
+        if isinstance(out, (tuple, list)):
+            return type(out)(o.as_subclass(torch.Tensor) if isinstance(o, BlockedTensor) and not is_split(o.dtype) else o for o in out)
+        return out
 
 
 def tag(t):
@@ -163,7 +170,16 @@ def pack_conv_weight(w, dtype, cin_mult=8, cout_mult=4, scale=1.0, sn=None):
     if w.is_cuda:
         from . import ops
         with ops.on_device(w):
-            return ops.pack_weights(w, dtype, op, ip, scale, None if sn is None else sn[0], None if sn is None else sn[1])
+            out = ops.pack_weights(w, dtype, op, ip, scale, None if sn is None else sn[0], None if sn is None else sn[1])
+            if is_split(dtype):
+                # same contract as the host path (split_halves raises OverflowError): 256 * W / sigma * scale must fit the half range.
+                # Checked once per packing on the packed hi halves (bytes 0-63 of every 128-byte block)
+                nblk = op * kh * kw * ip // 32
+                hi = untag(out).contiguous().view(torch.uint8).reshape(-1)[: nblk * 128].reshape(nblk, 128)[:, :64].contiguous().view(torch.float16)
+                if not bool(torch.isfinite(hi).all()):
+                    raise OverflowError("a conv weight does not fit the half range of the %s mode (|256 W| >= 65504)"
+                                        % ("fp16x3" if dtype == SPLIT_DTYPE else "fp16x2"))
+            return out
     w = w.detach().float()
     if sn is not None:
         w = sn_fold(w, sn[0], sn[1])
@@ -277,7 +293,7 @@ def equal_linear_scale(in_channels, lr_mul):
 # structure and the non-tensor leaves as JSON metadata, and a SHA-256 of each holder's parameters so that a blob is never
 # attached to different weights.
 PACK_FORMAT = "marconet_amd.packed.v2"
-PACK_LAYOUT = 4        # bump whenever any holder's _build() changes what it emits (keys, padding, layouts): a blob written by a
+PACK_LAYOUT = 5        # bump whenever any holder's _build() changes what it emits (keys, padding, layouts): a blob written by a
                        # different _build must not attach (it would fail with a KeyError mid-forward, or be read with another layout)
 
 

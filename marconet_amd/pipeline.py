@@ -124,9 +124,12 @@ class MarconetPipeline:
         """BASELINE configs[4]: a batch of strips of different content widths (each zero-padded to 512, i.e. -1 after
         Normalize, test_sr.py:100-115).  The encoder needs the 512-wide strip (its token-axis LayerNorm(64)/Linear(64,.)
         pin 64 tokens, models/textvit_arch.py:59-62,141-144); TSPSRNet is width-agnostic, so images are bucketed by
-        ``ceil(w_b / bucket) * bucket`` and each bucket runs the SR net at its own width W' with ``locs`` re-normalised
-        to W' (locs are centre / width, models/networks.py:426).  SURVEY.md §8d: the oracle of this mode is the reference
-        TSPSRNet called at the same W' — it is NOT equal to the 512-padded run (GroupNorm reduces over the whole map).
+        ``ceil(w_b / bucket) * bucket`` and each bucket runs the SR net at its own width W'.  Glyph centres are the INTEGER centres of
+        the 512-padded run the locs were normalised for — trunc(loc * 512) at the 32-row scale, trunc(loc * 1024) at the 64-row scale
+        (models/networks.py:426) — with the windows clipped to W' (2 W'); re-normalising loc to W' in fp32 could move a centre by one
+        pixel.  SURVEY.md §8d: the oracle of this mode is the reference TSPSRNet called at the same W' with locs that reproduce those
+        centres — it is NOT equal to the 512-padded run (GroupNorm reduces over the whole map; a window that crosses the bucket edge is
+        clipped there).
         → list (input order) of SR tensors [3, 128, 4·W'_b] fp32."""
         dev = lq.device
         B = lq.shape[0]

@@ -717,3 +717,41 @@ def test_style_rows_and_scaled_demod():
     assert float(((d1.cpu() - want).abs() / want).max()) <= 2e-7                     # rsqrt of an argument scaled by 4^-e
     r2, eps2, none = ops.style_rows(src.to(DEV), 0, 96)
     assert none is None and r2.shape == (7, 96) and float(r2[4].abs().max()) == 0.0 and float(eps2[4]) == 1.0
+
+
+@pytest.mark.parametrize("dtype", ALL_DTYPES)
+@pytest.mark.parametrize("c", [128, 512])
+def test_torgb_kernel(c, dtype):
+    """ToRGB.forward (models/networks.py:313-321): modulated 1x1 conv (no demodulation) + bias + bilinear x2 of the skip + tanh"""
+    ops = _ops()
+    n, h, w = 3, 6, 10
+    x = _q(_rnd((n, c, h, w), 90), dtype)
+    wt = _rnd((3, c), 91, 1.0 / math.sqrt(c))
+    style = _rnd((n, c), 92).abs() + 0.5
+    sb = _rnd((n, 1), 93).abs() + 0.5
+    bias = torch.cat([_rnd((3,), 94, 0.2), torch.zeros(1)])
+    skip = torch.tanh(_rnd((n, 3, h // 2, w // 2), 95))
+    skip4 = torch.cat([skip, torch.zeros(n, 1, h // 2, w // 2)], dim=1).permute(0, 2, 3, 1).contiguous()
+    conv = F.conv2d(x * style[:, :, None, None], wt.reshape(3, c, 1, 1)) * sb.reshape(n, 1, 1, 1) + bias[:3].reshape(1, 3, 1, 1)
+    for sk, ref in ((None, torch.tanh(conv)),
+                    (skip4, torch.tanh(conv + F.interpolate(skip, scale_factor=2, mode="bilinear", align_corners=False)))):
+        y = ops.torgb(_nhwc(x, dtype), wt.to(DEV), style.to(DEV), sb.to(DEV), bias.to(DEV), None if sk is None else sk.to(DEV))
+        torch.cuda.synchronize()
+        assert y.dtype == torch.float32 and y.shape == (n, h, w, 4) and float(y[..., 3].abs().max()) == 0.0
+        _check("torgb c=%d skip=%s %s" % (c, sk is not None, dtype), y[..., :3].cpu().permute(0, 3, 1, 2), ref, torch.float32)
+    y1 = ops.torgb(_nhwc(x, dtype), wt.to(DEV), style.to(DEV), None, bias.to(DEV), None)          # no scale_b
+    _check("torgb no scale_b %s" % dtype, y1[..., :3].cpu().permute(0, 3, 1, 2),
+           torch.tanh(F.conv2d(x * style[:, :, None, None], wt.reshape(3, c, 1, 1)) + bias[:3].reshape(1, 3, 1, 1)), torch.float32)
+
+
+def test_f16_diagnostic_tile_ids_are_refused():
+    """MNET_F16 LDS-DMA ids 11-15 are wrong-on-purpose diagnostic builds: not reachable through the C-ABI unless the process opts in"""
+    ops = _ops()
+    from marconet_amd._lib import MarconetHipError
+    x = _nhwc(_rnd((1, 64, 8, 16), 96), torch.float16)
+    wt = _pack_w(_rnd((64, 64, 3, 3), 97, 0.05), torch.float16)
+    for id_ in (11, 12, 13, 14, 15):
+        with pytest.raises(MarconetHipError, match="diagnostic"):
+            ops.conv2d(x, wt, 64, 3, 3, (1, 1), (1, 1), algo=16 + id_)
+    ops.conv2d(x, wt, 64, 3, 3, (1, 1), (1, 1), algo=16 + 3)          # a production id still launches
+    torch.cuda.synchronize()

@@ -269,7 +269,10 @@ def test_fp16x3_mixed_widths_and_reference_call_form(nets, ckpts):
             for b, wd in enumerate(widths):
                 wb = (wd + 63) // 64 * 64
                 _, a, c = O.tspgan_forward(ckpts[1], w[b:b + 1].repeat(counts[b], 1), labels[b])
-                ref = O.tspsr_forward(ckpts[2], lq[b:b + 1, :, :, :wb], [a], [c], locs[b:b + 1] * (512.0 / wb))
+                # the oracle (the reference's arithmetic at width W') is handed locs that reproduce the integer centres of the padded run:
+            # (c64 + 0.5) / (2 W') → trunc(. * 2 W') = c64 = trunc(loc * 1024) and trunc(. * W') = c64 >> 1 = trunc(loc * 512)
+            c64 = torch.trunc(locs[b:b + 1] * 1024.0)
+            ref = O.tspsr_forward(ckpts[2], lq[b:b + 1, :, :, :wb], [a], [c], (c64 + 0.5) / (2.0 * wb))
                 worst = max(worst, _err(outs[b], ref[0]))
         _note("sr.cfg5.fp16x3.bucketed.maxabs", worst)
         assert worst <= TOL
@@ -382,13 +385,20 @@ def test_config4_gan_only_large_batch(nets, ckpts):
 
 def test_config5_mixed_widths_bucketed(nets, ckpts):
     """BASELINE configs[4]: variable-width strips bucketed by padded width.  Oracle: the reference
-    TSPSRNet at the SAME bucket width with locs re-normalised to it; encoder and TSPGAN see the 512-padded strip."""
+    TSPSRNet at the SAME bucket width W' with the glyph centres of the 512-padded run — the integer centres trunc(loc * 512) /
+    trunc(loc * 1024) the locs were normalised for (re-normalising in fp32, loc * 512 / W' * W', can move a centre by one pixel);
+    encoder and TSPGAN see the 512-padded strip."""
     from marconet_amd.pipeline import MarconetPipeline
     widths = [130, 200, 512, 250, 128]
     counts = [2, 3, 4, 0, 1]
     lq = synth.make_lq(51, len(widths), widths)
     labels = [synth.make_labels(60 + i, c) for i, c in enumerate(counts)]
     locs = synth.make_locs(counts, widths)
+    # image 0 (bucket 192): a glyph whose window [169, 201) straddles the bucket edge, and a centre where the fp32 re-normalisation
+    # loc * (512 / 192) * 192 truncates differently from loc * 512
+    locs[0, 0] = 185.3 / 512.0
+    locs[0, 2] = 0.1601562350988388          # just below 82 / 512: trunc(loc * 512) = 81, trunc(fp32(loc * 512 / 192) * 192) = 82
+    assert int(torch.trunc(locs[0, 2] * 512.0)) == 81 and int(torch.trunc((locs[0, 2] * (512.0 / 192)) * 192.0)) == 82
     pipe = MarconetPipeline(*nets, precision="fp32")
     outs = pipe.forward_mixed_widths(lq.to(DEV), widths, [l.to(DEV) for l in labels], locs.to(DEV))
     worst = 0.0
@@ -400,7 +410,10 @@ def test_config5_mixed_widths_bucketed(nets, ckpts):
                 _, a, c = O.tspgan_forward(ckpts[1], w[b:b + 1].repeat(counts[b], 1), labels[b])
             else:
                 a, c = torch.zeros(0, 256, 64, 64), torch.zeros(0, 512, 32, 32)
-            ref = O.tspsr_forward(ckpts[2], lq[b:b + 1, :, :, :wb], [a], [c], locs[b:b + 1] * (512.0 / wb))
+            # the oracle (the reference's arithmetic at width W') is handed locs that reproduce the integer centres of the padded run:
+            # (c64 + 0.5) / (2 W') → trunc(. * 2 W') = c64 = trunc(loc * 1024) and trunc(. * W') = c64 >> 1 = trunc(loc * 512)
+            c64 = torch.trunc(locs[b:b + 1] * 1024.0)
+            ref = O.tspsr_forward(ckpts[2], lq[b:b + 1, :, :, :wb], [a], [c], (c64 + 0.5) / (2.0 * wb))
             assert outs[b].shape == (3, 128, 4 * wb)
             worst = max(worst, _err(outs[b], ref[0]))
     _note("sr.cfg5.fp32.bucketed.maxabs", worst)

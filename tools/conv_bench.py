@@ -3,6 +3,8 @@
 (interleaved rounds in one process, median of HIP-event timings).  python tools/conv_bench.py [--rounds 7]"""
 import argparse
 import os
+
+os.environ.setdefault("MNET_ALLOW_DIAGNOSTIC_KERNELS", "1")     # this tool pins the diagnostic f16 tile ids 11-15 on purpose
 import sys
 
 import torch
