@@ -269,10 +269,9 @@ def test_fp16x3_mixed_widths_and_reference_call_form(nets, ckpts):
             for b, wd in enumerate(widths):
                 wb = (wd + 63) // 64 * 64
                 _, a, c = O.tspgan_forward(ckpts[1], w[b:b + 1].repeat(counts[b], 1), labels[b])
-                # the oracle (the reference's arithmetic at width W') is handed locs that reproduce the integer centres of the padded run:
-            # (c64 + 0.5) / (2 W') → trunc(. * 2 W') = c64 = trunc(loc * 1024) and trunc(. * W') = c64 >> 1 = trunc(loc * 512)
-            c64 = torch.trunc(locs[b:b + 1] * 1024.0)
-            ref = O.tspsr_forward(ckpts[2], lq[b:b + 1, :, :, :wb], [a], [c], (c64 + 0.5) / (2.0 * wb))
+                # (the integer centres of the padded run, see test_config5_mixed_widths_bucketed)
+                c64 = torch.trunc(locs[b:b + 1] * 1024.0)
+                ref = O.tspsr_forward(ckpts[2], lq[b:b + 1, :, :, :wb], [a], [c], (c64 + 0.5) / (2.0 * wb))
                 worst = max(worst, _err(outs[b], ref[0]))
         _note("sr.cfg5.fp16x3.bucketed.maxabs", worst)
         assert worst <= TOL

@@ -18,10 +18,10 @@ def main():
     out = {}
     for b in re.split(r"\n(?=\S)", txt):
         lines = b.strip().split("\n")
-        m = re.match(r"void conv_dma_kernel<(\d+), (\d+), (\d+), (\d+), (\d+), (\d+), 0(?:, (\w+))?(?:, (\w+))?(?:, (\w+))?>", lines[0])
+        m = re.match(r"void conv_dma_kernel<(\d+), (\d+), (\d+), (\d+), (\d+), (\d+), 0(?:, (\w+))?(?:, (\w+))?(?:, (\w+))?(?:, (\w+))?>", lines[0])
         if not m:
             continue
-        x3, spread, pipe = m.group(7) in ("true", "1"), m.group(8) in ("true", "1"), m.group(9) in ("true", "1")
+        x3, spread, pipe, mx = (m.group(i) in ("true", "1") for i in (7, 8, 9, 10))
         c = {}
         for l in lines[1:]:
             q = re.match(r"\s+(\S+)\s+mean/dispatch\s+([\d.]+)\s+dispatches (\d+)", l)
@@ -29,7 +29,9 @@ def main():
                 c[q.group(1)] = (float(q.group(2)), int(q.group(3)))
         f, w = c["FETCH_SIZE"][0], c["WRITE_SIZE"][0]
         gui = c["GRBM_GUI_ACTIVE"][0] / 8.0
-        out["conv_dma_kernel<%s%s>%s" % (",".join(m.groups()[:6]), (",spread" if spread else "") + (",pipe" if pipe else ""), " f16x3" if x3 else "")] = {
+        key = ("conv_dma_kernel<%s,mx%s> f16x2" % (",".join(m.groups()[:6]), ",pipe" if pipe else "") if mx else
+               "conv_dma_kernel<%s%s>%s" % (",".join(m.groups()[:6]), (",spread" if spread else "") + (",pipe" if pipe else ""), " f16x3" if x3 else ""))
+        out[key] = {
             "hbm_bytes_per_launch": round((2 * f + w) * 1024),
             "FETCH_SIZE_KB_raw": f, "WRITE_SIZE_KB": w, "dispatches": c["FETCH_SIZE"][1],
             "l2_hit_rate": round(c["TCC_HIT_sum"][0] / (c["TCC_HIT_sum"][0] + c["TCC_MISS_sum"][0]), 4),
