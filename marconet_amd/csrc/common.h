@@ -256,7 +256,7 @@ static inline bool aligned128(const void* p) { return (reinterpret_cast<uintptr_
 
 __device__ __forceinline__ float act_apply(float v, int act) {
     switch (act) {
-        case MNET_ACT_RELU: return fmaxf(v, 0.f);
+        case MNET_ACT_RELU: return v < 0.f ? v * 0.f : v;         // (not fmaxf: a NaN must stay a NaN, like torch.relu; -inf becomes NaN, see act_apply_vec)
         case MNET_ACT_LRELU: return v > 0.f ? v : v * 0.2f;
         case MNET_ACT_LRELU_SQRT2: return (v > 0.f ? v : v * 0.2f) * 1.41421356237309515f;
         case MNET_ACT_TANH: return tanhf(v);
@@ -268,8 +268,10 @@ __device__ __forceinline__ float act_apply(float v, int act) {
 
 // Activation over N register values with ONE wave-uniform branch per activation kind.  (A per-element `switch (act)` in an
 // unrolled epilogue compiles to a scalar branch chain per value — ~1000 branches and ~100 KB of code in the 256x256 conv
-// kernel, measured at 10 us per workgroup.)  The cheap family is branch-free: (max(v,0) + min(v,0)*slope) * post, which
-// reproduces act_apply bit for bit (one of the two terms is zero; the products round exactly as there).
+// kernel, measured at 10 us per workgroup.)  The cheap family is branch-free: (v < 0 ? v * slope : v) * post (compare + select; ReLU is
+// slope 0, so relu(-inf) = NaN: an infinity only ever comes from a half-precision overflow and must stay visible),
+// which reproduces act_apply bit for bit AND keeps a NaN a NaN (the earlier max/min form, fmaxf(v,0) + fminf(v,0)*slope, turned NaN
+// into 0 — it swallowed the evidence of a half-precision overflow two layers after it happened).
 template <int N, bool CHEAP_ONLY = false>
 __device__ __forceinline__ void act_apply_vec(float* v, int act) {
     if (act == MNET_ACT_NONE) return;
@@ -278,7 +280,7 @@ __device__ __forceinline__ void act_apply_vec(float* v, int act) {
         const float slope = act == MNET_ACT_RELU ? 0.f : 0.2f;
         const float post = act == MNET_ACT_LRELU_SQRT2 ? 1.41421356237309515f : 1.f;
 #pragma unroll
-        for (int q = 0; q < N; ++q) v[q] = (fmaxf(v[q], 0.f) + fminf(v[q], 0.f) * slope) * post;
+        for (int q = 0; q < N; ++q) v[q] = (v[q] < 0.f ? v[q] * slope : v[q]) * post;
     } else if (act == MNET_ACT_TANH) {
 #pragma unroll
         for (int q = 0; q < N; ++q) v[q] = tanhf(v[q]);

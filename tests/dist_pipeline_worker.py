@@ -34,7 +34,7 @@ def main():
         lq = synthetic.make_lq(91, total, widths)
         labels = [synthetic.make_labels(900 + i, c) for i, c in enumerate(counts)]
         locs = synthetic.make_locs(counts, widths, max_glyphs=5)
-        for prec in ("fp32", "fp16x3", "fp16"):
+        for prec in ("fp32", "fp16x2", "fp16x3", "fp16"):
             pipe = MarconetPipeline(enc.eval().to(dev), gan.eval().to(dev), sr.eval().to(dev), precision=prec)
             for output in ("u8_bgr", "nchw_f32"):
                 full = pipe.forward_sharded(lq, labels, locs, output=output, force_collective=force)

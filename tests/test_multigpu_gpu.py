@@ -38,7 +38,7 @@ def test_sharded_forward_equals_single_gpu(total, tmp_path):
         assert p.wait(timeout=900) == 0
     res = json.load(open(out))
     assert res["world"] == world and res["backend"] == "nccl"
-    for k in ("fp32.u8_bgr", "fp32.nchw_f32", "fp16x3.u8_bgr", "fp16x3.nchw_f32", "fp16.u8_bgr", "fp16.nchw_f32"):
+    for k in ("fp32.u8_bgr", "fp32.nchw_f32", "fp16x2.u8_bgr", "fp16x2.nchw_f32", "fp16x3.u8_bgr", "fp16x3.nchw_f32", "fp16.u8_bgr", "fp16.nchw_f32"):
         assert res[k], "%s: gathered result differs from the single-GPU result" % k
 
 
@@ -51,6 +51,6 @@ def test_rccl_path_runs_in_a_world_of_one(tmp_path):
     assert p.wait(timeout=900) == 0
     res = json.load(open(out))
     assert res["world"] == 1 and res["backend"] == "nccl"
-    for k in ("fp32.u8_bgr", "fp32.nchw_f32", "fp16x3.u8_bgr", "fp16x3.nchw_f32", "fp16.u8_bgr", "fp16.nchw_f32",
-              "fp32.overlapped", "fp16x3.overlapped", "fp16.overlapped"):
+    for k in ("fp32.u8_bgr", "fp32.nchw_f32", "fp16x2.u8_bgr", "fp16x2.nchw_f32", "fp16x3.u8_bgr", "fp16x3.nchw_f32", "fp16.u8_bgr", "fp16.nchw_f32",
+              "fp32.overlapped", "fp16x2.overlapped", "fp16x3.overlapped", "fp16.overlapped"):
         assert res[k], "%s: result through the forced collective differs from forward_batch" % k
