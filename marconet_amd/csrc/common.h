@@ -38,14 +38,25 @@ template <typename To, typename From>
 __device__ __forceinline__ To bitcast(const From& v) { return __builtin_bit_cast(To, v); }
 
 __device__ __forceinline__ u32x4 ldg16(const void* p) { return *reinterpret_cast<const u32x4*>(p); }
-#ifndef MNET_NT_STORE
-#define MNET_NT_STORE 0      // 1: 16-byte stores of the streaming kernels bypass L2 allocation (A/B build: EXTRA_HIPCC_FLAGS=-DMNET_NT_STORE=1)
+__device__ __forceinline__ void stg16(void* p, u32x4 v) { *reinterpret_cast<u32x4*>(p) = v; }
+// 16-byte store of the HBM-bound streaming kernels (straw: up-sample, GroupNorm apply, AdaIN, scatter, converters).  A/B build
+// EXTRA_HIPCC_FLAGS=-DMNET_NT_STRAW=1 marks them non-temporal.  (Non-temporal stores in the CONV epilogues were measured: fp16x2
+// 197.7 -> 168.5 images/s — the seven 16-byte pieces of a 128-byte block then reach memory as partial-line writes.)
+#ifndef MNET_NT_STRAW
+#define MNET_NT_STRAW 0
 #endif
-__device__ __forceinline__ void stg16(void* p, u32x4 v) {
-#if MNET_NT_STORE
+__device__ __forceinline__ void stg16s(void* p, u32x4 v) {
+#if MNET_NT_STRAW
     __builtin_nontemporal_store(v, reinterpret_cast<u32x4*>(p));
 #else
     *reinterpret_cast<u32x4*>(p) = v;
+#endif
+}
+__device__ __forceinline__ void stg8s(void* p, u32x2 v) {
+#if MNET_NT_STRAW
+    __builtin_nontemporal_store(v, reinterpret_cast<u32x2*>(p));
+#else
+    *reinterpret_cast<u32x2*>(p) = v;
 #endif
 }
 
@@ -108,11 +119,11 @@ template <> __device__ __forceinline__ Raw<hs> ldraw<hs>(const hs* p) {
     const unsigned char* q = reinterpret_cast<const unsigned char*>(a - ((a >> 5) & 3u) * 16u);
     Raw<hs> r; r.hi = ldg16(q); r.lo = ldg16(q + 64); return r;
 }
-template <typename T> __device__ __forceinline__ void straw(T* p, const Raw<T>& r) { stg16(p, r.v); }
+template <typename T> __device__ __forceinline__ void straw(T* p, const Raw<T>& r) { stg16s(p, r.v); }
 template <> __device__ __forceinline__ void straw<hs>(hs* p, const Raw<hs>& r) {
     const uintptr_t a = reinterpret_cast<uintptr_t>(p);
     unsigned char* q = reinterpret_cast<unsigned char*>(a - ((a >> 5) & 3u) * 16u);
-    stg16(q, r.hi); stg16(q + 64, r.lo);
+    stg16s(q, r.hi); stg16s(q + 64, r.lo);
 }
 template <typename T> __device__ __forceinline__ Raw<T> zero_raw() { Raw<T> r; r.v = u32x4{0u, 0u, 0u, 0u}; return r; }
 template <> __device__ __forceinline__ Raw<hs> zero_raw<hs>() { Raw<hs> r; r.hi = u32x4{0u, 0u, 0u, 0u}; r.lo = r.hi; return r; }
@@ -173,10 +184,10 @@ template <> __device__ __forceinline__ void straw<hm>(hm* p, const Raw<hm>& r) {
     const uintptr_t a = reinterpret_cast<uintptr_t>(p);
     const unsigned s = (unsigned)(a >> 5) & 3u;
     unsigned char* blk = reinterpret_cast<unsigned char*>(a - s * 32u);
-    stg16(blk + s * 16u, r.hi);
-    *reinterpret_cast<u32x2*>(blk + 64 + hm_lo_slot((int)s) * 8) = r.lo8;
-    if (s == 0) stg16(blk + 96, u32x4{(unsigned)r.e8, 0u, 0u, 0u});       // the whole 128-byte line is written: no partial-line
-    if (s == 1) stg16(blk + 112, u32x4{0u, 0u, 0u, 0u});                  // write-back, deterministic padding
+    stg16s(blk + s * 16u, r.hi);
+    stg8s(blk + 64 + hm_lo_slot((int)s) * 8, r.lo8);
+    if (s == 0) stg16s(blk + 96, u32x4{(unsigned)r.e8, 0u, 0u, 0u});      // the whole 128-byte line is written: no partial-line
+    if (s == 1) stg16s(blk + 112, u32x4{0u, 0u, 0u, 0u});                 // write-back, deterministic padding
 }
 template <> __device__ __forceinline__ Raw<hm> zero_raw<hm>() { Raw<hm> r; r.hi = u32x4{0u, 0u, 0u, 0u}; r.lo8 = u32x2{0u, 0u}; r.e8 = 0; return r; }
 
