@@ -40,8 +40,9 @@ __device__ __forceinline__ To bitcast(const From& v) { return __builtin_bit_cast
 __device__ __forceinline__ u32x4 ldg16(const void* p) { return *reinterpret_cast<const u32x4*>(p); }
 __device__ __forceinline__ void stg16(void* p, u32x4 v) { *reinterpret_cast<u32x4*>(p) = v; }
 // 16-byte store of the HBM-bound streaming kernels (straw: up-sample, GroupNorm apply, AdaIN, scatter, converters).  A/B build
-// EXTRA_HIPCC_FLAGS=-DMNET_NT_STRAW=1 marks them non-temporal.  (Non-temporal stores in the CONV epilogues were measured: fp16x2
-// 197.7 -> 168.5 images/s — the seven 16-byte pieces of a 128-byte block then reach memory as partial-line writes.)
+// EXTRA_HIPCC_FLAGS=-DMNET_NT_STRAW=1 marks them non-temporal — measured on one box (bench.py, B = 256): fp16x2 203.1 -> 185.2
+// images/s (the 8-byte lo pieces of a block become partial-line writes), fp16x3 188.6 -> 188.1: off.  (Non-temporal stores in
+// the CONV epilogues: fp16x2 197.7 -> 168.5 images/s.)
 #ifndef MNET_NT_STRAW
 #define MNET_NT_STRAW 0
 #endif
