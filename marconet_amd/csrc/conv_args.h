@@ -14,6 +14,7 @@ struct ConvArgs {
     int ktiles, tilesC, ntiles;
     int split;               // MNET_F16X2 launch: c0 / c1 / cin / K are PHYSICAL (f16 view with twice the channels: per 32-channel block 32 hi
                              // halves then 32 lo halves); cout stays logical; the epilogue multiplies the accumulator by 2^-8 and stores hi/lo
+    int mx_fetch_pad;        // fp16+8 launches, A/B knob (env MNET_MX_FETCH_PAD=1): also fetch the padding chunk 7 of every activation block (whole 128-byte lines)
     int one_tile_per_wg;     // A/B knob (MNET_CONV_ALGO_FLAG_ONE_TILE): grid = #tiles instead of a persistent grid
 };
 

@@ -510,6 +510,8 @@ extern "C" double mnet_conv2d_flops(const mnet_conv_desc* d) {
 // argument validation shared by the launch and the planning entry points; fills the kernel-argument block
 static int conv_prepare(const mnet_conv_desc* d, int32_t algo, ConvArgs& a) {
     a.one_tile_per_wg = (algo & MNET_CONV_ALGO_FLAG_ONE_TILE) ? 1 : 0;
+    static const int env_fetch_pad = [] { const char* e = getenv("MNET_MX_FETCH_PAD"); return e ? atoi(e) : 0; }();   // A/B knob, see ConvArgs
+    a.mx_fetch_pad = env_fetch_pad;
     algo &= ~MNET_CONV_ALGO_FLAG_ONE_TILE;
     MNET_CHECK_ARG((algo >= 0 && algo <= 3) || (algo >= MNET_CONV_ALGO_DMA_CFG0 && algo < MNET_CONV_ALGO_DMA_CFG0 + 16) ||
                    (algo >= MNET_CONV_ALGO_STRIP_CFG0 && algo < MNET_CONV_ALGO_STRIP_CFG0 + 3) ||

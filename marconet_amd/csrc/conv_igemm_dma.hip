@@ -136,7 +136,7 @@ __global__ void __launch_bounds__(WC * WP * 64, WC * WP / 4) conv_dma_kernel(con
                 for (int r = 0; r < 8; ++r)
                     if (r < p.kh && (unsigned)(ih0 + r) < (unsigned)p.h) m |= cm << (r * p.kw);
                 xmask[j] = m;
-                if constexpr (MX) { if ((lcb >> 4) == 7u) xmask[j] = 0; }      // chunk 7 of an fp16+8 activation block is padding: not fetched
+                if constexpr (MX) { if ((lcb >> 4) == 7u && !p.mx_fetch_pad) xmask[j] = 0; }   // chunk 7 of an fp16+8 activation block is padding: not fetched
             }
         }
         cur_c = 0; cur_s = 0; cur_tap = 0; cur_tpx = 0; cur_k = 0;

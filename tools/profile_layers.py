@@ -60,13 +60,25 @@ def main():
         ms = s.elapsed_time(e)
         tot_conv += ms
         lines.append("%-4s n=%-5d %4dx%-4d c=%3d+%-3d -> %4d k%d s%s out %4dx%-4d %s%s%s%s%s act%d k%-2d %8.3f ms %8.1f TF/s %5.1f%%"
-                     % ({0: "f32", 1: "f16", 2: "x3 "}[r["dt"]], r["n"], r["h"], r["w"], r["c0"], r["c1"], r["cout"], r["k"], r["s"], r["ho"], r["wo"],
+                     % ({0: "f32", 1: "f16", 2: "x3 ", 3: "x2 "}[r["dt"]], r["n"], r["h"], r["w"], r["c0"], r["c1"], r["cout"], r["k"], r["s"], r["ho"], r["wo"],
                         "P" if r["pro"] else "-", "S" if r["sw"] else "-", "V" if r["vw"] else "-", "D" if r["osc"] else "-",
                         "R" if r["res"] else "-", r["act"], kid, ms, fl / ms / 1e9, 100 * ms / total))
+    # per (kernel id, dtype): launches, time, algorithmic FLOPs and algorithmic bytes (input(s) + output + residual + weights, each once)
+    per = {}
+    for r, (s, e, fl, d, kid) in zip(recs, ops.stats.events):
+        esz = {0: 4, 1: 2, 2: 4, 3: 4}[r["dt"]]
+        by = esz * (r["n"] * r["h"] * r["w"] * (r["c0"] + r["c1"]) + r["n"] * r["ho"] * r["wo"] * r["cout"] * (2 if r["res"] else 1)
+                    + r["cout"] * r["k"] * r["k"] * (r["c0"] + r["c1"]))
+        a_ = per.setdefault((kid, r["dt"]), [0, 0.0, 0.0, 0.0])
+        a_[0] += 1; a_[1] += s.elapsed_time(e); a_[2] += fl; a_[3] += by
+    lines.append("per kernel id (mnet_conv2d_plan) and dtype: launches, ms, algorithmic TFLOP per launch, algorithmic GB per launch, TFLOP/s")
+    for (kid, dt), (cnt, ms, fl, by) in sorted(per.items(), key=lambda kv: -kv[1][1]):
+        lines.append("  id %-3d %s  %3d launches  %9.3f ms  %7.3f TFLOP/launch  %7.3f GB/launch  %7.1f TFLOP/s"
+                     % (kid, {0: "f32", 1: "f16", 2: "x3 ", 3: "x2 "}[dt], cnt, ms, fl / cnt / 1e12, by / cnt / 1e9, fl / ms / 1e9))
     lines.append("step total %.2f ms, conv launches %.2f ms (%d), other %.2f ms" % (total, tot_conv, len(recs), total - tot_conv))
     os.makedirs(os.path.dirname(a.out), exist_ok=True)
     open(a.out, "w").write("\n".join(lines) + "\n")
-    print("\n".join(lines[-1:]))
+    print("\n".join(lines[-(len(per) + 2):]))
 
 
 if __name__ == "__main__":
