@@ -163,6 +163,9 @@ template <> __device__ __forceinline__ void st_elem<hs>(hs* px, int c, float v) 
 // (chunk j of a pixel at +32 j bytes).  A chunk of 8 channels = 8 hi halves + 8 lo bytes + the E8M0 exponent of ITS BLOCK's scale,
 // which is shared by the 4 chunks of the block: packr<hm> therefore reduces over the 4 lanes of a quad — every kernel that stores
 // hm chunks keeps chunk j of a pixel in lane j (mod 4) of a fully active quad (linear thread -> chunk maps, C % 32 == 0).
+#ifndef MNET_HM_SIMPLE_LOAD
+#define MNET_HM_SIMPLE_LOAD 0
+#endif
 struct hm { unsigned int bits; };
 static_assert(sizeof(hm) == 4, "hm is 4 bytes");
 template <> struct Vec<hm> { static constexpr int N = 8; };
@@ -171,14 +174,27 @@ template <> struct Raw<hm> { u32x4 hi; u32x2 lo8; int e8; };
 // 8-byte slot of the lo bytes of chunk s (channels 8 s .. 8 s + 7) inside the block's 32 lo bytes (order 0-7,16-23,8-15,24-31)
 __device__ __forceinline__ int hm_lo_slot(int s) { return ((s & 1) << 1) | (s >> 1); }
 
+// (quad-cooperative like straw<hm>: the 4 lanes of a quad load the 4 chunks of one block.)  Two 16-byte loads per lane — its hi
+// halves and one quarter of the block's second half (lanes 0 / 1: the lo bytes of chunks (0, 2) / (1, 3), lane 2: the scale byte) —
+// then five DPP moves hand every lane its own 8 lo bytes and the block's exponent.
 template <> __device__ __forceinline__ Raw<hm> ldraw<hm>(const hm* p) {
     const uintptr_t a = reinterpret_cast<uintptr_t>(p);
     const unsigned s = (unsigned)(a >> 5) & 3u;
     const unsigned char* blk = reinterpret_cast<const unsigned char*>(a - s * 32u);
     Raw<hm> r;
     r.hi = ldg16(blk + s * 16u);
+#if MNET_HM_SIMPLE_LOAD      // A/B build: three independent loads per lane (hi 16 B, lo 8 B, scale byte)
     r.lo8 = *reinterpret_cast<const u32x2*>(blk + 64 + hm_lo_slot((int)s) * 8);
     r.e8 = blk[96];
+    return r;
+#endif
+    const u32x4 q = ldg16(blk + 64 + (s < 3u ? s : 2u) * 16u);           // (lane 3 re-reads lane 2's chunk: no divergence, same line)
+    const unsigned a0 = (unsigned)__builtin_amdgcn_update_dpp(0, (int)q[0], 0x44, 0xf, 0xf, true);     // from lane (s & 1)
+    const unsigned a1 = (unsigned)__builtin_amdgcn_update_dpp(0, (int)q[1], 0x44, 0xf, 0xf, true);
+    const unsigned a2 = (unsigned)__builtin_amdgcn_update_dpp(0, (int)q[2], 0x44, 0xf, 0xf, true);
+    const unsigned a3 = (unsigned)__builtin_amdgcn_update_dpp(0, (int)q[3], 0x44, 0xf, 0xf, true);
+    r.lo8 = s < 2u ? u32x2{a0, a1} : u32x2{a2, a3};
+    r.e8 = __builtin_amdgcn_update_dpp(0, (int)q[0], 0xAA, 0xf, 0xf, true) & 0xff;                     // lane 2's first byte
     return r;
 }
 // (called with the 4 lanes of a quad active on the 4 chunks of ONE block, like packr<hm>.)  Every lane issues exactly two 16-byte
