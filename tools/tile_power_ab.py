@@ -48,11 +48,16 @@ def main():
     ap.add_argument("--n", type=int, default=64)
     ap.add_argument("--launches", type=int, default=0)
     ap.add_argument("--only", default="x3:11,x3:20,x2:6,x2:11")
+    ap.add_argument("--shape", default="", help="n,h,w,cin,cout of the 3x3 layer (default: --n,64,1024,256,256)")
+    ap.add_argument("--ragged", action="store_true", help="valid_w[n] = w - (n % 5) * 3 (glyph windows of different widths)")
     a = ap.parse_args()
     from marconet_amd import ops, packing
     dev = "cuda"
     torch.manual_seed(0)
     n, h, w, cin, cout = a.n, 64, 1024, 256, 256
+    if a.shape:
+        n, h, w, cin, cout = (int(v) for v in a.shape.split(","))
+    vw = torch.tensor([w - (i % 5) * 3 for i in range(n)], dtype=torch.int32, device=dev) if a.ragged else None
     x = torch.randn((n, h, w, cin), device=dev)
     wt = torch.randn((cout, cin, 3, 3), device=dev) * 0.02
     bias = torch.zeros(cout, device=dev)
@@ -64,7 +69,7 @@ def main():
     for arm in a.only.split(","):
         mode, i = arm.split(":")
         xs, ws, out = data[mode]
-        run = lambda: ops.conv2d(xs, ws, cout, 3, 3, (1, 1), (1, 1), bias=bias, act=ops.ACT_LRELU, out=out, algo=algo_of(int(i)))
+        run = lambda: ops.conv2d(xs, ws, cout, 3, 3, (1, 1), (1, 1), bias=bias, act=ops.ACT_LRELU, out=out, valid_w=vw, algo=algo_of(int(i)))
         for _ in range(3):
             run()
         torch.cuda.synchronize()
