@@ -26,7 +26,9 @@ template <int BP> struct StripCap { static constexpr int MINW = BP == 256 ? 16 :
 // X3: split-half launch (MNET_F16X2): the tensors are walked as f16 with twice the channels — a strip row / weight row of 128 bytes is
 //     one 32-channel block, hi halves in chunks 0-3, lo halves in chunks 4-7 — and every (slab, tap) is multiplied three times
 //     (hi*hi, hi*lo, lo*hi), exactly like conv_dma_kernel<…, X3>.
-template <int BC, int BP, int WC, int WP, bool X3 = false>
+// MX (with X3): fp16+8 launch (MNET_F16M) — the slab arithmetic of conv_dma_kernel<…, MX> (two v_mfma_f32_32x32x16_f16 + one block-scaled
+//     v_mfma_scale_f32_32x32x64_f8f6f4 per 32x32 output block and slab, same order) with the activation fragments read from the strip.
+template <int BC, int BP, int WC, int WP, bool X3 = false, bool MX = false>
 __global__ void __launch_bounds__(WC * WP * 64, WC * WP / 4) conv_strip_kernel(const ConvArgs p) {
     constexpr int NW = WC * WP;
     constexpr int FC = BC / WC / 16, FP = BP / WP / 16;
@@ -38,6 +40,7 @@ __global__ void __launch_bounds__(WC * WP * 64, WC * WP / 4) conv_strip_kernel(c
     static_assert(NW == 8 || NW == 16, "8 or 16 waves");
     static_assert(WJ >= 1 && WJ * 8 * NW == BC, "tile / wave-count mismatch");
     static_assert((BC / WC) % 64 == 0 && (BP / WP) % 32 == 0 && SCAP % 8 == 0, "wave tile shape");
+    static_assert(!MX || X3, "MX is a 4-byte storage mode");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];   // [W0][W1][S0][S1]
 
     const int tid = threadIdx.x, lane = tid & 63;
@@ -78,7 +81,7 @@ __global__ void __launch_bounds__(WC * WP * 64, WC * WP / 4) conv_strip_kernel(c
 #pragma unroll
         for (int j = 0; j < WJ; ++j) {
             const int row = (wave + NW * j) * 8 + rg;
-            const int ch = dma_weight_channel<16>(row);
+            const int ch = MX ? dma_weight_channel_mx(row) : dma_weight_channel<16>(row);
             const int lc = pc ^ ((row >> 1) & 7);
             woff[j] = (co0 + ch < p.cout) ? (unsigned)(ch * p.K * 2 + lc * 16) : OOB;
         }
@@ -171,6 +174,75 @@ __global__ void __launch_bounds__(WC * WP * 64, WC * WP / 4) conv_strip_kernel(c
         const int jr = W < BP ? pq / W : 0;
         srow[f] = jr * SW + (pq - jr * W);                     // + s selects the tap (strip column 0 is x = -1)
     }
+    // fp16+8: 32x32 fragments; lane = (row lane & 31, k half h = lane >> 5)
+    f32x16 acc32[MX ? FC / 2 : 1][MX ? FP / 2 : 1];
+    int srow32[MX ? FP / 2 : 1];
+    int mx_sa[MX ? FC / 2 : 1];
+    if constexpr (MX) {
+#pragma unroll
+        for (int f = 0; f < FP / 2; ++f) {
+            const int pq = wp * (BP / WP) + f * 32 + (lane & 31);
+            const int jr = W < BP ? pq / W : 0;
+            srow32[f] = jr * SW + (pq - jr * W);
+        }
+    }
+    auto compute_mx = [&](int wst, int sst, int s) __attribute__((always_inline)) {
+        const unsigned char* sw_ = smem + wst * WBYTES;
+        const unsigned char* ss_ = smem + 2 * WBYTES + sst * SBYTES;
+        const int l32 = lane & 31, h = lane >> 5;
+        constexpr int FA = FC / 2, FB = FP / 2;
+        u32x4 a[2][FA], bh[2][FB];
+#pragma unroll
+        for (int k2 = 0; k2 < 2; ++k2) {
+#pragma unroll
+            for (int f = 0; f < FA; ++f) a[k2][f] = *reinterpret_cast<const u32x4*>(sw_ + swz_dma(wc * (BC / WC) + f * 32 + l32, 2 * k2 + h));
+#pragma unroll
+            for (int f = 0; f < FB; ++f) bh[k2][f] = *reinterpret_cast<const u32x4*>(ss_ + swz_dma(srow32[f] + s, 2 * k2 + h));
+        }
+        i32x8 b8[FB], a8[FA];
+        int eb[FB];
+#pragma unroll
+        for (int f = 0; f < FB; ++f) {
+            const int R = srow32[f] + s;
+            const unsigned char* row = ss_ + R * 128;
+            const int sw3 = (R >> 1) & 7;
+            eb[f] = *(row + ((6 ^ sw3) << 4));
+            const u32x4 lo8 = *reinterpret_cast<const u32x4*>(row + (((4 + h) ^ sw3) << 4));
+            b8[f][4] = (int)lo8[0]; b8[f][5] = (int)lo8[1]; b8[f][6] = (int)lo8[2]; b8[f][7] = (int)lo8[3];
+        }
+#pragma unroll
+        for (int k2 = 0; k2 < 2; ++k2)
+#pragma unroll
+            for (int fa = 0; fa < FA; ++fa)
+#pragma unroll
+                for (int fb = 0; fb < FB; ++fb)
+                    acc32[fa][fb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bitcast<f16x8>(a[k2][fa]), bitcast<f16x8>(bh[k2][fb]), acc32[fa][fb], 0, 0, 0);
+#pragma unroll
+        for (int f = 0; f < FB; ++f) {
+            const float sc = __builtin_bit_cast(float, (unsigned)eb[f] << 23);
+#pragma unroll
+            for (int k2 = 0; k2 < 2; ++k2)
+#pragma unroll
+                for (int d = 0; d < 2; ++d) {
+                    s16x2 r = {0, 0};
+                    r = __builtin_amdgcn_cvt_scalef32_pk_fp8_f16(r, bitcast<f16x2>(bh[k2][f][2 * d]), sc, false);
+                    r = __builtin_amdgcn_cvt_scalef32_pk_fp8_f16(r, bitcast<f16x2>(bh[k2][f][2 * d + 1]), sc, true);
+                    b8[f][2 * k2 + d] = bitcast<int>(r);
+                }
+        }
+#pragma unroll
+        for (int f = 0; f < FA; ++f) {
+            const u32x4 lo8 = *reinterpret_cast<const u32x4*>(sw_ + swz_dma(wc * (BC / WC) + f * 32 + l32, 4 + 2 * h));
+            const u32x4 hi8 = *reinterpret_cast<const u32x4*>(sw_ + swz_dma(wc * (BC / WC) + f * 32 + l32, 5 + 2 * h));
+            a8[f] = i32x8{(int)lo8[0], (int)lo8[1], (int)lo8[2], (int)lo8[3], (int)hi8[0], (int)hi8[1], (int)hi8[2], (int)hi8[3]};
+        }
+#pragma unroll
+        for (int fa = 0; fa < FA; ++fa)
+#pragma unroll
+            for (int fb = 0; fb < FB; ++fb)
+                acc32[fa][fb] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a8[fa], b8[fb], acc32[fa][fb], 0, 0, 0, mx_sa[fa], 0, eb[fb]);
+    };
+
     auto compute_half = [&](int wst, int sst, int s, int ks) __attribute__((always_inline)) {
         const unsigned char* sw_ = smem + wst * WBYTES;
         const unsigned char* ss_ = smem + 2 * WBYTES + sst * SBYTES;
@@ -228,6 +300,22 @@ __global__ void __launch_bounds__(WC * WP * 64, WC * WP / 4) conv_strip_kernel(c
         for (int a = 0; a < FC; ++a)
 #pragma unroll
             for (int b = 0; b < FP; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if constexpr (MX) {
+#pragma unroll
+            for (int a = 0; a < FC / 2; ++a)
+#pragma unroll
+                for (int b = 0; b < FP / 2; ++b)
+#pragma unroll
+                    for (int q = 0; q < 16; ++q) acc32[a][b][q] = 0.f;
+            int co0_, pix0_;
+            tile_coords(c_v, co0_, pix0_);
+            const unsigned char* wexp = reinterpret_cast<const unsigned char*>(p.wgt) + (size_t)p.cout * p.K * 2;
+#pragma unroll
+            for (int f = 0; f < FC / 2; ++f) {
+                const int ch = co0_ + dma_weight_channel_mx(wc * (BC / WC) + f * 32 + (lane & 31));
+                mx_sa[f] = ch < p.cout ? (int)wexp[ch] : 0;      // (every slab waits vmcnt(0): these loads need no extra fence)
+            }
+        }
         int s = 0;                                             // tap column of slab kt (kt % 3)
         // hot iterations: both cursors stay inside this tile (the weight cursor crosses at kt = nk-1, the strip cursor at nk-3)
         for (int kt = 0; kt < nk - 3; ++kt) {
@@ -236,7 +324,8 @@ __global__ void __launch_bounds__(WC * WP * 64, WC * WP / 4) conv_strip_kernel(c
             asm volatile("" ::: "memory");
             issue_w_hot();
             if (s == 0) issue_s_hot();
-            if constexpr (X3) compute_x3(c_wst, c_sst, s);
+            if constexpr (MX) compute_mx(c_wst, c_sst, s);
+            else if constexpr (X3) compute_x3(c_wst, c_sst, s);
             else { compute_half(c_wst, c_sst, s, 0); compute_half(c_wst, c_sst, s, 1); }
             c_wst ^= 1;
             if (++s == 3) { s = 0; c_sst ^= 1; }
@@ -249,22 +338,24 @@ __global__ void __launch_bounds__(WC * WP * 64, WC * WP / 4) conv_strip_kernel(c
             asm volatile("" ::: "memory");
             issue_w();
             if (t == 0) issue_s();
-            if constexpr (X3) compute_x3(c_wst, c_sst, t);
+            if constexpr (MX) compute_mx(c_wst, c_sst, t);
+            else if constexpr (X3) compute_x3(c_wst, c_sst, t);
             else { compute_half(c_wst, c_sst, t, 0); compute_half(c_wst, c_sst, t, 1); }
             c_wst ^= 1;
         }
         c_sst ^= 1;
         int co0, pix0;
         tile_coords(c_v, co0, pix0);
-        dma_epilogue<BC, BP, WC, WP, 16, 0, FC, FP, X3>(p, acc, acc32_unused, co0, pix0, wc, wp, lane);
+        if constexpr (MX) dma_epilogue_mx<BC, BP, WC, WP, FC, FP>(p, acc32, co0, pix0, wc, wp, lane);
+        else dma_epilogue<BC, BP, WC, WP, 16, 0, FC, FP, X3>(p, acc, acc32_unused, co0, pix0, wc, wp, lane);
     }
 }
 
-template <int BC, int BP, int WC, int WP, bool X3 = false>
+template <int BC, int BP, int WC, int WP, bool X3 = false, bool MX = false>
 static int launch_strip_cfg(const ConvArgs& a, hipStream_t st) {
     constexpr int LDS = 2 * BC * 128 + 2 * StripCap<BP>::ROWS * 128;
     static_assert(LDS <= 160 * 1024, "LDS budget");
-    auto kern = conv_strip_kernel<BC, BP, WC, WP, X3>;
+    auto kern = conv_strip_kernel<BC, BP, WC, WP, X3, MX>;
     static thread_local DeviceOnce attr_once;      // per instantiation, per thread, per device
     if (!attr_once.done()) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
@@ -289,8 +380,8 @@ int conv_strip_pick(const ConvArgs& a, int dtype, bool explicit_request) {
     // 256x256 tiles: measured neutral (89.8 + 5.1 vs 94.5 ms per bench step; 128-VGPR budget of its 16 waves is exhausted,
     // 20 spills) — AUTO keeps the per-tap kernel there unless MNET_STRIP_256=1; the 64x512 tile (8 waves) gains 20 %.
     static const bool auto256 = [] { const char* e = getenv("MNET_STRIP_256"); return e && atoi(e) != 0; }();
-    if ((dtype != MNET_F16 && dtype != MNET_F16X2) || !conv_dma_eligible(a, dtype)) return -1;
-    if (dtype == MNET_F16X2 && a.cout >= 128) return -1;                   // split-half: the 64x512 tile only (the big tiles take the 8-wave per-tap forms)
+    if ((dtype != MNET_F16 && dtype != MNET_F16X2 && dtype != MNET_F16M) || !conv_dma_eligible(a, dtype)) return -1;
+    if (dtype != MNET_F16 && a.cout >= 128) return -1;                   // split-half: the 64x512 tile only (the big tiles take the 8-wave per-tap forms)
     if (a.cout >= 256 && !explicit_request && !auto256) return -1;
     if (a.kh != 3 || a.kw != 3 || a.sh != 1 || a.sw != 1 || a.ph != 1 || a.pw != 1 || a.c1 != 0 || a.x1) return -1;
     if (a.ho != a.h || a.wo != a.w) return -1;
@@ -311,6 +402,10 @@ int conv_strip_pick(const ConvArgs& a, int dtype, bool explicit_request) {
 }
 
 int launch_conv_strip(const ConvArgs& a, hipStream_t st, int cfg) {
+    if (a.split == 2) {
+        if (cfg == 1) return launch_strip_cfg<64, 512, 1, 8, true, true>(a, st);
+        return mnet_fail(MNET_E_ARG, "conv: strip configuration %d has no fp16+8 form", cfg);
+    }
     if (a.split) {
         if (cfg == 1) return launch_strip_cfg<64, 512, 1, 8, true>(a, st);
         return mnet_fail(MNET_E_ARG, "conv: strip configuration %d has no split-half form", cfg);

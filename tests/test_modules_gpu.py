@@ -253,14 +253,15 @@ def test_fp16x3_batched_driver_and_batch_invariance(prec, nets, ckpts):
         pipe.set_precision("fp32")
 
 
-def test_fp16x3_mixed_widths_and_reference_call_form(nets, ckpts):
-    """configs[4] in the split-half mode: bucketed widths (row gathers of split-half priors) against the oracle at the bucket width"""
+@pytest.mark.parametrize("prec", ["fp16x3", "fp16x2"])
+def test_fp16x3_mixed_widths_and_reference_call_form(prec, nets, ckpts):
+    """configs[4] in the split-half / fp16+8 modes: bucketed widths (row gathers of blocked-storage priors) against the oracle at the bucket width"""
     from marconet_amd.pipeline import MarconetPipeline
     widths, counts = [130, 512, 250], [2, 4, 3]
     lq = synth.make_lq(171, len(widths), widths)
     labels = [synth.make_labels(180 + i, c) for i, c in enumerate(counts)]
     locs = synth.make_locs(counts, widths)
-    pipe = MarconetPipeline(*nets, precision="fp16x3")
+    pipe = MarconetPipeline(*nets, precision=prec)
     try:
         outs = pipe.forward_mixed_widths(lq.to(DEV), widths, labels, locs)          # labels / locs on the host
         worst = 0.0
@@ -273,7 +274,7 @@ def test_fp16x3_mixed_widths_and_reference_call_form(nets, ckpts):
                 c64 = torch.trunc(locs[b:b + 1] * 1024.0)
                 ref = O.tspsr_forward(ckpts[2], lq[b:b + 1, :, :, :wb], [a], [c], (c64 + 0.5) / (2.0 * wb))
                 worst = max(worst, _err(outs[b], ref[0]))
-        _note("sr.cfg5.fp16x3.bucketed.maxabs", worst)
+        _note("sr.cfg5." + prec + ".bucketed.maxabs", worst)
         assert worst <= TOL
     finally:
         pipe.set_precision("fp32")
@@ -296,7 +297,7 @@ def test_style_normalisation_is_exact_and_removes_the_half_precision_hazard(nets
         big = {k: (v * 3e4 if ".modulation." in k else v) for k, v in ckpts[1].items()}
         g2 = networks.TSPGAN()
         g2.load_state_dict(big, strict=True)
-        g2 = g2.eval().to(DEV).set_precision("fp16x3")
+        g2 = g2.eval().to(DEV).set_precision("fp16x3")          # (the fp16+8 mode shares the hi half and its range)
         with torch.no_grad():
             ref = O.tspgan_forward(big, styles, labels)
         out = g2(styles=styles.to(DEV), labels=labels.to(DEV), noise=None)

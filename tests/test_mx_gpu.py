@@ -363,7 +363,7 @@ def _fuzz_cases():
         n = rng.randint(1, 2) if big else rng.randint(1, 9)
         cases.append((n, h, w, cin - c1, c1, cout, k, stride))
     cases += [(4, 64, 64, 64, 0, 256, 3, (1, 1)), (2, 128, 128, 128, 0, 64, 3, (1, 1)), (300, 16, 16, 64, 0, 128, 3, (1, 1)),
-              (1, 32, 2048, 96, 0, 64, 3, (1, 1))]
+              (1, 32, 2048, 96, 0, 64, 3, (1, 1)), (4, 128, 128, 64, 0, 64, 3, (1, 1)), (64, 32, 32, 32, 0, 96, 3, (1, 1))]       # strip kernel (cout < 128)
     return cases
 
 

@@ -41,7 +41,7 @@ def main():
               ("resnet_8x512_512to512", a.n * 4, 8, 512, 512, 512, ((11, SP), (6, MX), (11, MX))),
               ("sr_final_256to128", a.n // 2, 64, 1024, 256, 128, ((9, SP), (21, SP), (7, MX), (8, MX), (12, MX))),
               ("gan_128_128", a.n * 4, 128, 128, 128, 128, ((9, SP), (7, MX), (8, MX), (12, MX))),
-              ("sr_final_64", a.n // 2, 128, 2048, 64, 64, ((-1, SP), (5, SP), (5, MX), (13, MX)))]
+              ("sr_final_64", a.n // 2, 128, 2048, 64, 64, ((-1, SP), (5, SP), (5, MX), (13, MX), (-1, MX)))]
     for name, n, h, w, cin, cout, algos in shapes:
         x = torch.randn((n, h, w, cin), device=dev)
         wt = torch.randn((cout, cin, 3, 3), device=dev) * 0.02
