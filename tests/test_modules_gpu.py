@@ -503,7 +503,7 @@ def test_full_size_batch_properties_fp16(nets, precision):
 
 @pytest.mark.parametrize("precision", ["fp16x2", "fp16x3"])
 def test_full_size_batch_sampled_against_the_oracle(nets, ckpts, precision):
-    """the full-size batch (64 strips x 16 glyphs, what bench.py runs per --batch 64) in the parity-meeting throughput modes, with SIX of
+    """the full-size batch (64 strips x 16 glyphs, what bench.py runs per --batch 64) in the parity-meeting throughput modes, with THREE of
     its strips — spread over the batch, i.e. over different pixel / glyph tiles of every big launch — recomputed by the CPU oracle one
     at a time like test_sr.py:77: <= 1e-3 each (the full-size test was property-only)"""
     from marconet_amd.pipeline import MarconetPipeline
@@ -515,10 +515,10 @@ def test_full_size_batch_sampled_against_the_oracle(nets, ckpts, precision):
     try:
         y = pipe.forward_batch(lq.to(DEV), labels, locs).cpu()
         worst = 0.0
-        for b in (0, 13, 27, 38, 50, 63):
+        for b in (0, 27, 63):
             r = O.end_to_end(ckpts[0], ckpts[1], ckpts[2], lq[b:b + 1], [labels[b]], locs[b:b + 1])
             worst = max(worst, (y[b:b + 1] - r["sr"]).abs().max().item())
-        _note("sr.%s.full_batch_64x16.sampled6.maxabs" % precision, worst)
+        _note("sr.%s.full_batch_64x16.sampled3.maxabs" % precision, worst)
         assert worst <= TOL
     finally:
         pipe.set_precision("fp32")
