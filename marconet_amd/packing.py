@@ -47,6 +47,10 @@ class BlockedTensor(torch.Tensor):
     @classmethod
     def __torch_function__(cls, func, types, args=(), kwargs=None):
         name = getattr(func, "__name__", None) or str(func)
+        if _TAG_GUARD and name == "to":          # device moves only: a dtype conversion would reinterpret the tag numerically
+            for v in list(args[1:]) + list((kwargs or {}).values()):
+                if isinstance(v, torch.dtype) and not is_split(v):
+                    raise TypeError("marconet_amd: .to(%s) on a blocked-storage tensor — use ops.convert / packing.to_float" % v)
         if _TAG_GUARD and name not in cls._ALLOWED:
             raise TypeError("marconet_amd: %s() on a blocked-storage tensor (%s tag): these bytes are only meaningful to the HIP kernels "
                             "— convert with ops.convert(t, torch.float32) / packing.to_float(t) first" % (name, "split-half / fp16+8"))

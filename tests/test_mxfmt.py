@@ -83,9 +83,11 @@ def test_blocked_storage_tensors_refuse_arithmetic():
     for dt in (packing.SPLIT_DTYPE, packing.MX_DTYPE):
         s = packing.from_float(x, dt)
         assert isinstance(s, packing.BlockedTensor) and s.dtype == dt and s.shape == x.shape
-        for bad in (lambda: s + s, lambda: s * 2.0, lambda: s.sum(), lambda: s.float(), lambda: torch.isfinite(s), lambda: torch.add(s, 1), lambda: s.abs()):
+        for bad in (lambda: s + s, lambda: s * 2.0, lambda: s.sum(), lambda: s.float(), lambda: torch.isfinite(s), lambda: torch.add(s, 1), lambda: s.abs(),
+                    lambda: s.to(torch.float32), lambda: s.to("cpu", torch.float16)):
             with pytest.raises(TypeError):
                 bad()
+        assert isinstance(s.to("cpu"), packing.BlockedTensor) and s.to("cpu").dtype == dt          # device moves stay allowed
         part = s[1:]
         assert isinstance(part, packing.BlockedTensor) and isinstance(s.clone(), packing.BlockedTensor) and isinstance(s.contiguous(), packing.BlockedTensor)
         assert part.data_ptr() == s.data_ptr() + 3 * 4 * 64 * 4 and s.is_contiguous() and s.numel() == x.numel() and s.element_size() == 4
