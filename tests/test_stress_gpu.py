@@ -7,6 +7,8 @@ variants of the synthetic checkpoints (marconet_amd/synthetic.py) and compared w
     FloatingPointError, not return garbage);
   * activations pushed down to ~1e-3 and below (the lo halves become fp16 subnormals);
   * near-tie logits (top-2 gaps of 1e-5 .. 1e-4 found by scanning seeds with linear_cls at gain 1.0)."""
+import functools
+
 import pytest
 import torch
 
@@ -17,6 +19,13 @@ pytestmark = pytest.mark.gpu
 DEV = "cuda"
 TOL = 1e-3
 MODES = ["fp32", "fp16x3", "fp16x2"]
+
+
+@functools.lru_cache(maxsize=None)
+def _encoder_sd(**kw):
+    """one state_dict object per variant, shared by the precision cases (4 s to build; its identity keys conftest's oracle memo)"""
+    from marconet_amd import synthetic
+    return synthetic.make_encoder_state_dict(**kw)
 
 
 def _encoder(sd, prec):
@@ -37,8 +46,7 @@ def _cmp(name, got, ref):
 def test_encoder_at_reference_init_and_scaled_ranges(prec, input_gain):
     """ResNet at the reference's own init gain (|feature| up to ~3e3), x8 (~2.4e4, a factor 2.7 under the fp16 limit) and x2^-20
     (~3e-3: most values below the fp16 normal range, every lo half subnormal): logits / w / locs <= 1e-3, indices exact"""
-    from marconet_amd import synthetic
-    sd = synthetic.make_encoder_state_dict(resnet_gain=1.0, input_gain=input_gain)
+    sd = _encoder_sd(resnet_gain=1.0, input_gain=input_gain)
     lq = synth.make_lq(7, 2, [512, 400])
     with torch.no_grad():
         r_logits, r_locs, r_w = O.encoder_forward(sd, lq)
@@ -50,12 +58,12 @@ def test_encoder_at_reference_init_and_scaled_ranges(prec, input_gain):
 
 
 @pytest.mark.parametrize("prec", ["fp16", "fp16x3", "fp16x2"])
-def test_overflow_raises_instead_of_returning_garbage(prec):
+def test_overflow_raises_instead_of_returning_garbage(prec, ckpts):
     """activations past 65504 in a half-range mode: the pipeline raises FloatingPointError (the fp32 mode handles the same weights)"""
-    from marconet_amd import networks, synthetic
+    from marconet_amd import networks
     from marconet_amd.pipeline import MarconetPipeline
-    sde = synthetic.make_encoder_state_dict(resnet_gain=1.0, input_gain=64.0)          # ResNet features up to ~1.9e5
-    sdg, sds = synthetic.make_gan_state_dict(), synthetic.make_sr_state_dict()
+    sde = _encoder_sd(resnet_gain=1.0, input_gain=64.0)          # ResNet features up to ~1.9e5
+    sdg, sds = ckpts[1], ckpts[2]
     enc, gan, sr = networks.TextContextEncoderV2(), networks.TSPGAN(), networks.TSPSRNet()
     enc.load_state_dict(sde); gan.load_state_dict(sdg); sr.load_state_dict(sds)
     pipe = MarconetPipeline(enc.eval().to(DEV), gan.eval().to(DEV), sr.eval().to(DEV), precision=prec)
@@ -77,8 +85,7 @@ def test_near_tie_logits(prec):
     """linear_cls at gain 1.0 (narrow top-2 gaps).  Claim checked: the logits deviate by <= 3e-5 in every parity mode (fp16x2 runs the
     encoder's ResNet in fp16x3), hence every position whose top-2 gap exceeds 1e-4 gets the reference's index; below that the
     chosen index is one of the reference's top two (fp32 summation order of either implementation decides)"""
-    from marconet_amd import synthetic
-    sd = synthetic.make_encoder_state_dict(cls_gain=1.0)
+    sd = _encoder_sd(cls_gain=1.0)
     lq = torch.cat([synth.make_lq(seed, 8, [512] * 8)[b:b + 1] for seed, b in NEAR_TIES])
     with torch.no_grad():
         r_logits = O.encoder_forward(sd, lq)[0]
