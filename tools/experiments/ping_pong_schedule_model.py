@@ -114,7 +114,32 @@ def run(total, rng):
     assert all(l == total - 1 for l in loaded)
 
 
+def check_addresses():
+    """the LOAD block reaches the other chunks of an LDS row by XOR on one address (4 address registers instead of 8): equal to
+    swz_dma(row, chunk) of conv_dma_common.h for every lane, fragment, stage and both tile geometries"""
+    def swz(row, chunk):
+        return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4)
+    for bc, bp, wc_n, wp_n in ((256, 256, 2, 4), (128, 512, 1, 8)):
+        fa, fb, stage = bc // wc_n // 32, bp // wp_n // 32, (bc + bp) * 128
+        for wave in range(8):
+            wc, wp = wave // wp_n, wave % wp_n
+            for lane in range(64):
+                l32, h = lane & 31, lane >> 5
+                ra, rb = wc * (bc // wc_n) + l32, wp * (bp // wp_n) + l32
+                for st in (0, 1):
+                    so = st * stage
+                    aa, a8a, ba, bea = swz(ra, h) + so, swz(ra, 4 + 2 * h) + so, swz(rb, h) + so + bc * 128, swz(rb, 6) + so + bc * 128
+                    for f in range(fa):
+                        assert aa + f * 4096 == so + swz(ra + 32 * f, h) and (aa ^ 32) + f * 4096 == so + swz(ra + 32 * f, 2 + h)
+                        assert a8a + f * 4096 == so + swz(ra + 32 * f, 4 + 2 * h) and (a8a ^ 16) + f * 4096 == so + swz(ra + 32 * f, 5 + 2 * h)
+                    for f in range(fb):
+                        sx = so + bc * 128
+                        assert ba + f * 4096 == sx + swz(rb + 32 * f, h) and (ba ^ 32) + f * 4096 == sx + swz(rb + 32 * f, 2 + h)
+                        assert (ba ^ 64) + f * 4096 == sx + swz(rb + 32 * f, 4 + h) and bea + f * 4096 == sx + swz(rb + 32 * f, 6)
+
+
 def main():
+    check_addresses()
     rng = random.Random(1234)
     for total in (1, 2, 3, 4, 5, 9, 18):
         for _ in range(400):
