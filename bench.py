@@ -158,12 +158,30 @@ def conv_roofline(ops, steps, alg_gf_step, prefer_dtype, batch=None, precision=N
                                 "(%s, batch %s, %s): not reported" % (os.path.basename(tpath), tj.get("measured_at", "round 1"), tj.get("batch", 64), tj.get("precision", "fp16")))
         except Exception as e:      # noqa: BLE001
             traffic_note = "profiles/%s unreadable: %s" % (os.path.basename(tpath), e)
+    # north_star's unit: ALGORITHMIC TFLOP/s against the dense fp16 MFMA peak (2500; 157.3 for the exact-fp32 mode).  The ceiling of the
+    # precision mode itself (peak / MFMA time units per product) is reported beside it, never as `frac`
+    ns_peak = PEAK_F32_TFLOPS if dom[1] == 0 else PEAK_F16_TFLOPS
+    tail = {}
+    for s_, e_, nb, name in ops.stats.tail_events:
+        r = tail.setdefault(name, [0.0, 0.0, 0])
+        r[0] += s_.elapsed_time(e_); r[1] += nb; r[2] += 1
+    tail_ms = sum(v[0] for v in tail.values()) / max(steps, 1)
+    tail_bytes = sum(v[1] for v in tail.values()) / max(steps, 1)
+    hbm_tail = {
+        "bound": "hbm", "ms_per_step": round(tail_ms, 3), "bytes": round(tail_bytes, 1),
+        "GB_per_s": round(tail_bytes / max(tail_ms, 1e-9) / 1e6, 1), "peak_GB_per_s": 8000.0,
+        "frac": round(tail_bytes / max(tail_ms, 1e-9) / 1e6 / 8000.0, 4),
+        "bytes_note": "algorithmic: every input and output tensor of a launch once, in its storage type (4 bytes per element in the fp16x2 / fp16x3 modes)",
+        "by_kernel": {k: {"ms_per_step": round(v[0] / max(steps, 1), 3), "GB_per_s": round(v[1] / max(v[0], 1e-9) / 1e6, 1), "launches_per_step": v[2] // max(steps, 1)}
+                      for k, v in sorted(tail.items(), key=lambda kv: -kv[1][0])},
+    }
     return {
-        "bound": "mfma", "achieved": round(achieved, 2), "peak": round(peak, 1), "unit": "TFLOP/s",
-        "frac": round(achieved / peak, 4), "frac_of_fp16_dense": round(achieved / PEAK_F16_TFLOPS, 4),
+        "bound": "mfma", "achieved": round(achieved, 2), "peak": round(ns_peak, 1), "unit": "TFLOP/s",
+        "frac": round(achieved / ns_peak, 4), "mode_peak": round(peak, 1), "frac_of_mode_peak": round(achieved / peak, 4),
         "executed_mfma_tflops": round(achieved * MFMA_UNITS[dom[1]], 1),
-        "peak_note": "peak = 2500 TFLOP/s dense fp16 MFMA / %.0f fp16-MFMA time units per algorithmic product in this mode; executed_mfma_tflops = "
-                     "achieved x units (fp16-equivalent matrix-pipe work), frac_of_fp16_dense = achieved / 2500" % MFMA_UNITS[dom[1]],
+        "peak_note": "achieved = algorithmic FLOPs / kernel time; peak = 2500 TFLOP/s dense fp16 MFMA (north_star's unit; 157.3 in the fp32 mode); mode_peak = "
+                     "peak / %.0f fp16-MFMA time units per algorithmic product in this mode; executed_mfma_tflops = achieved x units" % MFMA_UNITS[dom[1]],
+        "hbm_tail": hbm_tail,
         "traffic": traffic, "traffic_source": traffic_note,
         "kernel": kn + " " + DTNAME[dom[1]],
         "launches_per_step": dom_n // max(steps, 1),
@@ -171,14 +189,15 @@ def conv_roofline(ops, steps, alg_gf_step, prefer_dtype, batch=None, precision=N
         "flops_per_launch_avg": round(dom_fl / max(dom_n, 1), 1),
         "kernel_ms_per_step": round(dom_ms / max(steps, 1), 3),
         "all_conv_kernels": {
-            "achieved": round(alg_gf_step / max(main_ms, 1e-9), 2), "frac": round(alg_gf_step / max(main_ms, 1e-9) / peak, 4),
+            "achieved": round(alg_gf_step / max(main_ms, 1e-9), 2), "frac": round(alg_gf_step / max(main_ms, 1e-9) / ns_peak, 4),
+            "frac_of_mode_peak": round(alg_gf_step / max(main_ms, 1e-9) / peak, 4),
             "ms_per_step": round(main_ms, 3), "ms_per_step_all_dtypes": round(all_ms, 3),
             "algorithmic_gflop_per_step": round(alg_gf_step, 1),
             "launched_gflop_per_step": round(sum(v[1] for v in per.values()) / max(steps, 1) / 1e9, 1),
             "by_kernel_ms_per_step": {kname(k[0], k[1]) + " " + DTNAME[k[1]]: round(v[0] / max(steps, 1), 3)
                                       for k, v in sorted(per.items())},
         },
-    }, peak
+    }, ns_peak
 
 
 def main():
@@ -300,6 +319,12 @@ def main():
     ops.stats.enabled = ops.stats.timing = False
     if y.dtype.is_floating_point:
         assert torch.isfinite(y).all()
+    # the timed batch's OWN output, sampled: one strip per generator chunk (4096 glyphs / glyph_chunk 1024 = 4 chunks at the default
+    # configuration) — compared with the oracle below (the batch-256 step is the only place where the glyph loop of
+    # MarconetPipeline._core runs more than once)
+    samp_idx = sorted(set([0, B // 3, (2 * B) // 3, B - 1])) if a.config == "sr" else []
+    y_timed = y[samp_idx].float().cpu() if (a.config == "sr" and y.dtype.is_floating_point and y.dim() == 4 and y.shape[1] == 3) else None
+    y_timed_noimg = None
     total_images, per_rank_images = images_per_step, [images_per_step]
     if world > 1:
         t = torch.tensor([images_per_step], device=dev, dtype=torch.float64)
@@ -315,8 +340,11 @@ def main():
         # the same step without the generator's 128-px structure image, which only feeds test_sr.py's saved visualisation
         pipe.need_prior_image = False
         step()
-        dt2, _, _ = timed(step, fence, a.steps, world, dev)
+        dt2, _, y2 = timed(step, fence, a.steps, world, dev)
         pipe.need_prior_image = True
+        if y_timed is not None:
+            y_timed_noimg = y2[samp_idx].float().cpu()
+        del y2
         secondary = {"images_per_s_without_prior_image": round(total_images * a.steps / dt2, 3), "ms_per_step": round(dt2 / a.steps * 1e3, 3),
                      "note": "opt-in MarconetPipeline(need_prior_image=False): TSPGAN stops at the 64-px level; SR output identical"}
         # the other precision modes on the same batch (fp32: a 16-image slice — 54 images/s): the mode that meets the parity bar
@@ -369,7 +397,7 @@ def main():
                                 "(split-half storage, three f16 MFMA products) both meet the north-star parity bar (<= 1e-3, indices bit-exact; see "
                                 "parity); the plain fp16 storage mode — BASELINE configs[1]'s type, ~1e-2 deviation — and the exact fp32 mode are "
                                 "secondary.*_mode_images_per_s" % a.precision)
-    roofline["end_to_end_frac_of_peak"] = round(out["value"] / world * gf_image / 1e3 / peak, 4)
+    roofline["end_to_end_frac_of_peak"] = round(out["value"] / world * gf_image / 1e3 / peak, 4)          # of the dense fp16 (fp32-mode: fp32) MFMA peak
     if world > 1 or a.force_gather:
         out["ranks"] = {"world_size": dist.get_world_size(), "backend": dist.get_backend(),
                         "per_rank_images_per_s": [round(c_ * a.steps / t_, 2) for c_, t_ in zip(per_rank_images, per_rank_dt)]}
@@ -377,13 +405,14 @@ def main():
     # ---- CPU baseline (the oracle = port of the reference's CPU forward) + parity, rank 0 at N=1 only
     if rank == 0 and world == 1 and a.cpu_images > 0 and a.config == "sr":
         from oracle import marconet_oracle as O
-        k = a.cpu_images
+        k = min(a.cpu_images, len(samp_idx))
+        sel = samp_idx[:k]                       # the strips the oracle recomputes: spread over the timed batch (one per generator chunk)
         # the threads actually used: the affinity mask, capped (oneDNN convs at batch 1 stop scaling well before
         # that, and 256 oversubscribed threads on a cgroup-limited box measured 100x slower)
         threads = host_threads(a.cpu_threads)
         torch.set_num_threads(threads)
-        lq_c, locs_c = lq[:k].cpu(), locs[:k]
-        lab_c = labels[:k]
+        lq_c, locs_c = lq[sel].cpu(), locs[sel]
+        lab_c = [labels[i] for i in sel]
         O.end_to_end(sde, sdg, sds, lq_c[:1], [lab_c[0][:2]], locs_c[:1])          # warm-up (small)
         t0 = time.perf_counter()
         refs = [O.end_to_end(sde, sdg, sds, lq_c[i:i + 1], lab_c[i:i + 1], locs_c[i:i + 1]) for i in range(k)]  # batch 1, like test_sr.py:77
@@ -410,11 +439,17 @@ def main():
                 pipe.set_precision(prec)
             except ValueError:
                 continue
-            yk = pipe.forward_batch(lq[:k], labels[:k], locs[:k])
-            lg = pipe.encoder(lq[:k])[0]
+            yk = pipe.forward_batch(lq[sel].contiguous(), lab_c, locs_c)
+            lg = pipe.encoder(lq[sel].contiguous())[0]
             par["sr_max_abs_%s" % prec] = round((yk.cpu() - ref_sr).abs().max().item(), 6)
             par["argmax_match_%s" % prec] = round(float((lg.argmax(-1).cpu() == ref_arg).float().mean()), 4)
         pipe.set_precision(a.precision)
+        if y_timed is not None:       # the timed batch itself (all B strips in one call, the generator in chunks), at the sampled strips
+            par["sr_max_abs_%s_timed_batch" % a.precision] = round((y_timed[:k] - ref_sr).abs().max().item(), 6)
+            if y_timed_noimg is not None:
+                par["sr_max_abs_%s_timed_batch_without_prior_image" % a.precision] = round((y_timed_noimg[:k] - ref_sr).abs().max().item(), 6)
+                par["timed_batch_without_prior_image_equals_default"] = bool(torch.equal(y_timed, y_timed_noimg))
+            par["timed_batch_strips"] = sel
         par["bar"] = "north_star: <= 1e-3 max-abs on the SR output, argmax bit-exact (argmax_match == 1.0)"
         out["parity"] = par
     elif rank == 0 and world == 1 and a.cpu_images > 0 and a.config == "gan":

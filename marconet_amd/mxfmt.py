@@ -69,6 +69,8 @@ def pack_weight(w):
     assert I % 32 == 0
     wb = (w.detach().float() * WSCALE).reshape(O, KH, KW, I // 32, 32)
     hi = wb.to(torch.float16)
+    if not bool(torch.isfinite(hi).all()):          # the same contract as the split-half host packer and the device packer (mnet_pack_weights)
+        raise OverflowError("a conv weight does not fit the half range of the fp16x2 mode (|256 W| >= 65504)")
     lo = wb - hi.float()
     m = hi.float().abs().reshape(O, -1).amax(-1)
     e8 = (_floor_log2(m) - 7 + 127).clamp(11, 254).to(torch.int32)          # per output channel

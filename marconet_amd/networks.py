@@ -245,7 +245,7 @@ class TextGenerator(nn.Module):
         s, _, sb = self._mod(L, self._gidx, bcast=1)
         return ops.torgb(x, L["w"], s, sb, L["bias"], skip)
 
-    def forward_nhwc(self, styles, labels, need_image=True, style_index=None, p64_out=None, p32_out=None):
+    def forward_nhwc(self, styles, labels, need_image=True, style_index=None, p64_out=None, p32_out=None, image_precision=None):
         """→ (image NHWC fp32 [N,128,128c,4] (RGB0), prior64 NHWC [N,64,64c,256], prior32 NHWC [N,32,32c,512]).
         ``style_index`` (int64 [N], optional): ``styles`` then holds only the DISTINCT style vectors (one per image in
         test_sr.py:183, where every glyph of an image gets the same w) and glyph i uses styles[style_index[i]] — the style
@@ -253,9 +253,13 @@ class TextGenerator(nn.Module):
         ``p64_out`` / ``p32_out``: preallocated NHWC [N,64,64,256] / [N,32,32,512] views the two prior levels are written into by
         the producing conv itself (the batched driver hands slices of its all-glyph buffers: no concatenation pass afterwards).
         ``need_image=False`` (opt-in, batched SR driver only) stops after the 64-px level: the 128-px level feeds nothing
-        but the visualisation image (models/networks.py:148-164; 35 % of the generator's FLOPs) and ``image`` is None."""
+        but the visualisation image (models/networks.py:148-164; 35 % of the generator's FLOPs) and ``image`` is None.
+        ``image_precision`` (batched SR driver only, which never returns ``image``): precision mode of the levels BEHIND the two
+        prior levels — they feed nothing but the structure image (:161-164), so the driver keeps the reference's work but does not
+        spend SR-grade arithmetic on it; prior64 / prior32 (and hence the SR output) are bit-identical with and without it."""
         pk = self._cache.get(self, self.precision, self._build)
         dtype = torch_dtype(self.precision)
+        pk_img = pk if image_precision in (None, self.precision) else self._cache.get(self, image_precision, self._build)
         lat = ops.pixelnorm(styles)                                            # :170-171
         for w, b in pk["mlp"]:
             lat = ops.linear(lat, w, self.style_dim, bias=b, act=ops.ACT_LRELU_SQRT2)
@@ -270,7 +274,11 @@ class TextGenerator(nn.Module):
         for lvl in range(len(pk["rgbs"])):
             if not need_image and p64 is not None and p32 is not None:
                 return None, p64, p32
-            La, Lb = pk["convs"][2 * lvl], pk["convs"][2 * lvl + 1]
+            pkl = pk
+            if pk_img is not pk and p64 is not None and p32 is not None:      # image-only levels (see ``image_precision``)
+                pkl = pk_img
+                x = ops.convert(x, torch_dtype(image_precision))
+            La, Lb = pkl["convs"][2 * lvl], pkl["convs"][2 * lvl + 1]
             sa, da = self._style(La)
             sb, db = self._style(Lb)
             xu = ops.upsample2x(x, scale=sa)                                   # bilinear ×2 (:293) with ·s_a fused

@@ -112,9 +112,22 @@ class _Stats:
         self.conv_flops = 0.0
         self.conv_launches = 0
         self.events = []       # (start, end, flops, dtype, kernel id from mnet_conv2d_plan)
+        self.tail_events = []  # HBM-bound kernels: (start, end, algorithmic bytes — every tensor of the launch once —, name)
 
     def conv_time_ms(self):
         return sum(ev[0].elapsed_time(ev[1]) for ev in self.events)
+
+    def tail(self, name, tensors, launch):
+        """run ``launch()``; in an instrumented pass (bench.py's roofline pass) bracket it with HIP events on the launch stream and
+        book the storage bytes of ``tensors`` (inputs and outputs, each once) under ``name``"""
+        if not (self.enabled and self.timing):
+            return launch()
+        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        s.record()
+        r = launch()
+        e.record()
+        self.tail_events.append((s, e, float(sum(t.numel() * t.element_size() for t in tensors if t is not None)), name))
+        return r
 
 
 stats = _Stats()
@@ -210,7 +223,7 @@ def nchw_to_nhwc(src, dtype, c_ld=None):
     n, c, h, w = src.shape
     c_ld = c_ld or c
     dst = new_tensor((n, h, w, c_ld), dtype, src.device)
-    _lib.check(lib.mnet_nchw_to_nhwc(_p(src), _p(dst), _dt(dst), n, c, h, w, c_ld, _stream()), "mnet_nchw_to_nhwc")
+    stats.tail("layout", (src, dst), lambda: _lib.check(lib.mnet_nchw_to_nhwc(_p(src), _p(dst), _dt(dst), n, c, h, w, c_ld, _stream()), "mnet_nchw_to_nhwc"))
     return dst
 
 
@@ -221,7 +234,7 @@ def nhwc_to_nchw(src, c=None):
     n, h, w, c_ld = src.shape
     c = c or c_ld
     dst = torch.empty((n, c, h, w), dtype=torch.float32, device=src.device)
-    _lib.check(lib.mnet_nhwc_to_nchw(_p(src), _dt(src), _p(dst), n, c, h, w, c_ld, _stream()), "mnet_nhwc_to_nchw")
+    stats.tail("layout", (src, dst), lambda: _lib.check(lib.mnet_nhwc_to_nchw(_p(src), _dt(src), _p(dst), n, c, h, w, c_ld, _stream()), "mnet_nhwc_to_nchw"))
     return dst
 
 
@@ -232,8 +245,8 @@ def upsample2x(src, scale=None):
     _need_cuda(src, scale)
     n, h, w, c = src.shape
     dst = new_tensor((n, 2 * h, 2 * w, c), src.dtype, src.device)
-    _lib.check(lib.mnet_upsample2x_scale_nhwc(_p(src), _p(dst), _dt(src), n, h, w, c, _p(scale), _stream()),
-               "mnet_upsample2x_scale_nhwc")
+    stats.tail("upsample2x", (src, dst), lambda: _lib.check(lib.mnet_upsample2x_scale_nhwc(_p(src), _p(dst), _dt(src), n, h, w, c, _p(scale), _stream()),
+                                                            "mnet_upsample2x_scale_nhwc"))
     return dst
 
 
@@ -244,8 +257,8 @@ def affine_act(x, scale, shift=None, swish=False, out=None):
     _need_cuda(x, scale, shift, out)
     n, h, w, c = x.shape
     y = tag(torch.empty_like(x)) if out is None else out
-    _lib.check(lib.mnet_affine_act_nhwc(_p(x), _p(y), _dt(x), n, h * w, c, _p(scale), _p(shift), 1 if swish else 0,
-                                        _stream()), "mnet_affine_act_nhwc")
+    stats.tail("groupnorm_apply", (x, y), lambda: _lib.check(lib.mnet_affine_act_nhwc(_p(x), _p(y), _dt(x), n, h * w, c, _p(scale), _p(shift), 1 if swish else 0,
+                                                                                   _stream()), "mnet_affine_act_nhwc"))
     return y
 
 
@@ -259,8 +272,8 @@ def groupnorm_affine(x, gamma, beta, eps=1e-6, valid_w=None):
     partial = torch.empty((n * slices * (c // 32) * 2,), dtype=torch.float64, device=x.device)
     scale = torch.empty((n, c), dtype=torch.float32, device=x.device)
     shift = torch.empty((n, c), dtype=torch.float32, device=x.device)
-    _lib.check(lib.mnet_groupnorm_affine(_p(x), _dt(x), n, h, w, c, _p(valid_w), _p(gamma), _p(beta), eps,
-                                         _p(partial), slices, _p(scale), _p(shift), _stream()), "mnet_groupnorm_affine")
+    stats.tail("groupnorm_stats", (x,), lambda: _lib.check(lib.mnet_groupnorm_affine(_p(x), _dt(x), n, h, w, c, _p(valid_w), _p(gamma), _p(beta), eps,
+                                                                                  _p(partial), slices, _p(scale), _p(shift), _stream()), "mnet_groupnorm_affine"))
     return scale, shift
 
 
@@ -301,13 +314,14 @@ def adain_crop_concat_gn(prior, feat, g_img, g_x1, g_y1, g_w, gamma, beta, eps=1
         slices = 16
         partial = torch.empty((G * slices * C * 4,), dtype=torch.float64, device=prior.device)
         stat = torch.empty((G, 4, C), dtype=torch.float32, device=prior.device)
-        _lib.check(lib.mnet_adain_crop_concat_split(_p(prior), _p(feat), _p(out), _dt(prior), G, S, C, FW, _p(g_img), _p(g_x1),
-                                                    _p(g_y1), _p(g_w), _p(gamma), _p(beta), eps, _p(scale), _p(shift),
-                                                    _p(partial), _p(stat), slices, _stream()), "mnet_adain_crop_concat_split")
+        stats.tail("adain", (prior, prior, out), lambda: _lib.check(lib.mnet_adain_crop_concat_split(
+            _p(prior), _p(feat), _p(out), _dt(prior), G, S, C, FW, _p(g_img), _p(g_x1), _p(g_y1), _p(g_w), _p(gamma), _p(beta), eps, _p(scale), _p(shift),
+            _p(partial), _p(stat), slices, _stream()), "mnet_adain_crop_concat_split"))
         return out, scale, shift
-    _lib.check(lib.mnet_adain_crop_concat_gn(_p(prior), _p(feat), _p(out), _dt(prior), G, S, C, FW, _p(g_img), _p(g_x1),
-                                             _p(g_y1), _p(g_w), _p(gamma), _p(beta), eps, _p(scale), _p(shift), _stream()),
-               "mnet_adain_crop_concat_gn")
+    # bytes: the prior, a window of feat of the prior's size, the concatenated output
+    stats.tail("adain", (prior, prior, out), lambda: _lib.check(lib.mnet_adain_crop_concat_gn(
+        _p(prior), _p(feat), _p(out), _dt(prior), G, S, C, FW, _p(g_img), _p(g_x1), _p(g_y1), _p(g_w), _p(gamma), _p(beta), eps, _p(scale), _p(shift), _stream()),
+        "mnet_adain_crop_concat_gn"))
     return out, scale, shift
 
 
@@ -317,8 +331,8 @@ def glyph_scatter_affine(feat, scale, shift, g_start, g_x1, g_w):
     _need_cuda(feat, scale, shift, g_start, g_x1, g_w)
     B, S, FW, C = feat.shape
     out = tag(torch.empty_like(feat))
-    _lib.check(lib.mnet_glyph_scatter_affine(_p(feat), _p(scale), _p(shift), _p(out), _dt(feat), B, S, C, FW,
-                                             _p(g_start), _p(g_x1), _p(g_w), _stream()), "mnet_glyph_scatter_affine")
+    stats.tail("glyph_scatter", (feat, scale, shift, out), lambda: _lib.check(lib.mnet_glyph_scatter_affine(
+        _p(feat), _p(scale), _p(shift), _p(out), _dt(feat), B, S, C, FW, _p(g_start), _p(g_x1), _p(g_w), _stream()), "mnet_glyph_scatter_affine"))
     return out
 
 
@@ -414,7 +428,7 @@ def convert(x, dtype):
     lib = _lib.load()
     _need_cuda(x)
     y = new_tensor(x.shape, dtype, x.device)
-    _lib.check(lib.mnet_convert(_p(x), _dt(x), _p(y), _dt(y), x.numel(), _stream()), "mnet_convert")
+    stats.tail("convert", (x, y), lambda: _lib.check(lib.mnet_convert(_p(x), _dt(x), _p(y), _dt(y), x.numel(), _stream()), "mnet_convert"))
     return y
 
 
@@ -509,7 +523,7 @@ def torgb(x, wgt, style, scale_b, bias, skip=None):
     if skip is not None and (skip.dtype != torch.float32 or tuple(skip.shape) != (n, h // 2, w // 2, 4)):
         raise RuntimeError("torgb: skip must be fp32 [N,H/2,W/2,4]")
     out = torch.empty((n, h, w, 4), dtype=torch.float32, device=x.device)
-    _lib.check(lib.mnet_torgb(_p(x), _dt(x), n, h, w, c, _p(wgt), _p(style), _p(scale_b), _p(bias), _p(skip), _p(out), _stream()), "mnet_torgb")
+    stats.tail("torgb", (x, skip, out), lambda: _lib.check(lib.mnet_torgb(_p(x), _dt(x), n, h, w, c, _p(wgt), _p(style), _p(scale_b), _p(bias), _p(skip), _p(out), _stream()), "mnet_torgb"))
     return out
 
 
@@ -525,5 +539,5 @@ def conv3x3_rgb(x, wgt, bias, act=ACT_TANH, nhwc=True, nchw=False):
         raise RuntimeError("conv3x3_rgb: weight dtype/shape mismatch")
     y1 = torch.empty((n, h, w, 8), dtype=odt, device=x.device) if nhwc else None
     y2 = torch.empty((n, 3, h, w), dtype=torch.float32, device=x.device) if nchw else None
-    _lib.check(lib.mnet_conv3x3_rgb(_p(x), _dt(x), n, h, w, c, _p(wgt), _p(bias), act, _p(y1), _p(y2), _stream()), "mnet_conv3x3_rgb")
+    stats.tail("conv3x3_rgb", (x, y1, y2), lambda: _lib.check(lib.mnet_conv3x3_rgb(_p(x), _dt(x), n, h, w, c, _p(wgt), _p(bias), act, _p(y1), _p(y2), _stream()), "mnet_conv3x3_rgb"))
     return y1, y2

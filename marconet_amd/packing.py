@@ -44,6 +44,9 @@ class BlockedTensor(torch.Tensor):
         "is_pinned", "as_subclass", "_make_subclass", "requires_grad_", "is_shared", "share_memory_", "nbytes", "itemsize",
         "view_as", "reshape_as", "t_copy", "alias", "is_set_to", "_is_view", "is_same_size", "dim_order"))
 
+    _LAYOUT_CHECKED = frozenset(("__getitem__", "view", "reshape", "flatten", "unsqueeze", "squeeze", "narrow", "select", "index_select",
+                                 "chunk", "split", "unbind", "expand", "view_as", "reshape_as"))
+
     @classmethod
     def __torch_function__(cls, func, types, args=(), kwargs=None):
         name = getattr(func, "__name__", None) or str(func)
@@ -55,6 +58,17 @@ class BlockedTensor(torch.Tensor):
             raise TypeError("marconet_amd: %s() on a blocked-storage tensor (%s tag): these bytes are only meaningful to the HIP kernels "
                             "— convert with ops.convert(t, torch.float32) / packing.to_float(t) first" % (name, "split-half / fp16+8"))
         out = super().__torch_function__(func, types, args, kwargs or {})
+        # plumbing is over OUTER dimensions only: the last dimension carries whole 32-channel / 128-byte blocks, so a result that is
+        # still tagged must keep it (t[..., :8], t.narrow(-1, 0, 8), t.reshape(2, 192) would hand the kernels misaligned blocks)
+        if _TAG_GUARD and name in cls._LAYOUT_CHECKED and args and isinstance(args[0], BlockedTensor):
+            with torch._C.DisableTorchFunctionSubclass():
+                last = args[0].shape[-1] if args[0].dim() else None
+                for o in (out if isinstance(out, (tuple, list)) else (out,)):
+                    if last is not None and isinstance(o, BlockedTensor) and is_split(o.dtype) and (
+                            o.dim() == 0 or o.shape[-1] != last or (o.stride(-1) != 1 and o.shape[-1] > 1)):
+                        raise TypeError("marconet_amd: %s() changed the channel dimension of a blocked-storage tensor (%d -> %s): blocks of "
+                                        "32 channels / 128 bytes must stay whole — slice, view and concatenate over the outer dimensions only"
+                                        % (name, last, tuple(o.shape)))
         # a view under another dtype (``t.view(torch.uint8)``, ``.view(torch.float16)``: raw bytes / halves for the host-side packers)
         # is an ordinary tensor again
         if isinstance(out, BlockedTensor):

@@ -20,7 +20,8 @@ _NO_STYLE_DEDUPE = bool(int(_os.environ.get("MNET_NO_STYLE_DEDUPE", "0")))      
 
 
 class MarconetPipeline:
-    def __init__(self, encoder, gan, sr, precision=None, glyph_chunk=1024, need_prior_image=True, check_finite=None):
+    def __init__(self, encoder, gan, sr, precision=None, glyph_chunk=1024, need_prior_image=True, check_finite=None,
+                 prior_image_precision="auto"):
         """``precision``: None → MARCONET_PRECISION or "fp32" (the parity mode, ≤1e-3 vs the CPU reference).  The fp16
         storage modes are opt-in: plain "fp16" stores activations as one half (max 65504, 11 significant bits) and has only
         been validated on O(1)-activation synthetic checkpoints — with trained StyleGAN-type weights a modulated activation
@@ -34,7 +35,16 @@ class MarconetPipeline:
         # True (default): the generator also produces its 128-px structure image, as test_sr.py:183 does (it is only ever
         # used for the saved visualisation, test_sr.py:203-232).  False is an opt-in for throughput serving.
         self.need_prior_image = need_prior_image
+        # precision mode of the generator levels that feed only that image (forward_batch never returns it): "auto" = plain fp16 in
+        # the fp16x2 / fp16x3 modes, the mode's own arithmetic otherwise; None = always the mode's own.  The priors and the SR output
+        # do not depend on it (tests/test_modules_gpu.py::test_prior_image_precision_leaves_sr_bits_unchanged)
+        self.prior_image_precision = prior_image_precision
         self.set_precision(precision)
+
+    def _image_precision(self):
+        if self.prior_image_precision == "auto":
+            return "fp16" if self.precision in ("fp16x2", "fp16x3") else None
+        return self.prior_image_precision
 
     def _checks(self):
         return self.check_finite if self.check_finite is not None else self.precision != "fp32"
@@ -97,10 +107,10 @@ class MarconetPipeline:
                 e = min(G, s + self.glyph_chunk)
                 if _NO_STYLE_DEDUPE:
                     tg.forward_nhwc(w.index_select(0, img_of[s:e]).contiguous(), lab[s:e].contiguous(),
-                                    need_image=self.need_prior_image, p64_out=p64[s:e], p32_out=p32[s:e])
+                                    need_image=self.need_prior_image, p64_out=p64[s:e], p32_out=p32[s:e], image_precision=self._image_precision())
                     continue
                 tg.forward_nhwc(w, lab[s:e].contiguous(), need_image=self.need_prior_image, style_index=img_of[s:e].contiguous(),
-                                p64_out=p64[s:e], p32_out=p32[s:e])
+                                p64_out=p64[s:e], p32_out=p32[s:e], image_precision=self._image_precision())
             sr_dtype = torch_dtype(self.sr.precision)                 # the three nets may run in different precision modes
             p64, p32 = ops.convert(p64, sr_dtype), ops.convert(p32, sr_dtype)
         else:
@@ -154,7 +164,8 @@ class MarconetPipeline:
             if int(lab.min()) < 0 or int(lab.max()) >= tg.class_num:
                 raise RuntimeError("label index out of range [0,%d)" % tg.class_num)
             img_of = torch.repeat_interleave(torch.arange(B, device=dev), torch.tensor(counts, device=dev))
-            _, p64, p32 = tg.forward_nhwc(w.index_select(0, img_of).contiguous(), lab, need_image=self.need_prior_image)
+            _, p64, p32 = tg.forward_nhwc(w.index_select(0, img_of).contiguous(), lab, need_image=self.need_prior_image,
+                                          image_precision=self._image_precision())
         out = [None] * B
         flags = []
         for wb in sorted(set(widths)):
@@ -315,9 +326,21 @@ class GraphedForward:
             self.graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(self.graph):
                 self.out = pipe._core(self.lq, self.lab, self.img_of, self.counts, None, self.tables, output=output)
+            # the finiteness flag THIS graph refreshes on every replay (pipe._finite is reassigned by every other forward of the
+            # pipe — an eager forward_batch, another GraphedForward — and must not be read here)
+            self._flag = pipe._finite
+            self._checks = pipe._checks()
+
+    def raise_if_not_finite(self):
+        """reads this graph's own flag (one device→host synchronisation) — for callers that replay with check=False and test later"""
+        if self._flag is not None and not bool(self._flag):
+            raise FloatingPointError("marconet_amd: non-finite SR output in %s mode (activations beyond the fp16 range 65504?) — use "
+                                     "precision='fp32' for these weights" % self.pipe.precision)
 
     @torch.no_grad()
-    def __call__(self, lq, labels, locs):
+    def __call__(self, lq, labels, locs, check=None):
+        """``check``: None = as the pipe was configured at capture (on for the half-range modes: one flag read back, i.e. one
+        synchronisation per replay); False = no read-back on the latency path — call raise_if_not_finite() when the output is consumed"""
         from .glyphs import GlyphTables
         counts = [int(l.shape[0]) for l in labels]
         if counts != self.counts or tuple(lq.shape) != tuple(self.lq.shape):
@@ -330,7 +353,8 @@ class GraphedForward:
             GlyphTables(lh, counts, self.widths[0], 16, "cpu").copy_into(self.tables[0])
             GlyphTables(lh, counts, self.widths[1], 32, "cpu").copy_into(self.tables[1])
         self.graph.replay()
-        self.pipe._raise_if_not_finite()          # the flag tensor is part of the captured graph (refreshed by the replay)
+        if self._checks if check is None else check:
+            self.raise_if_not_finite()
         return self.out
 
 

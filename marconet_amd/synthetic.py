@@ -137,7 +137,19 @@ _GAN_CONVS = [(512, 512)] * 6 + [(512, 256), (256, 256), (256, 128), (128, 128)]
 _GAN_RGB_IN = [512, 512, 512, 256, 128]                                            # to_rgbs.0..4
 
 
-def make_gan_state_dict(seed=1234):
+def _apply_outliers(sd, outliers, skip=()):
+    """stress variants (tests/test_stress_gpu.py): ``outliers`` = {state_dict key: (index along dim 0, gain)} — that slice of the tensor is
+    multiplied by ``gain``, which puts ONE outlier channel into a 32-channel storage block of the consuming layer's activations"""
+    for key, (idx, gain) in (outliers or {}).items():
+        if key in skip:
+            continue
+        if key not in sd:
+            raise KeyError("outlier key %s not in this state_dict" % key)
+        sd[key] = sd[key].clone()
+        sd[key][idx] *= float(gain)
+
+
+def make_gan_state_dict(seed=1234, outliers=None):
     """Keys of ``TSPGAN`` (models/networks.py:51-164), all under ``TextGenerator.``"""
     sd = {}
     P = "TextGenerator."
@@ -170,10 +182,14 @@ def make_gan_state_dict(seed=1234):
         torgb(P + "to_rgbs.%d" % i, cin)
     # reference key order: style_mlp, input_text, conv1, to_rgb1, convs, to_rgbs (insertion order above
     # differs only in that; load_state_dict is order-independent)
+    _apply_outliers(sd, outliers)
     return sd
 
 
 # ----------------------------------------------------------------------------- SR checkpoint
+_SN_ROW_GAIN = {}      # make_sr_state_dict(outliers=...): weight_orig rows scaled BEFORE the power iteration (sigma stays the true spectral norm)
+
+
 def _sn_conv(sd, seed, key, cout, cin, k=3, iters=40):
     """Old-style torch.nn.utils.spectral_norm parametrisation (models/networks.py:14,336-405):
     ``weight_orig`` (Parameter), ``weight_u`` / ``weight_v`` (buffers), ``bias``; eval-mode weight is
@@ -181,6 +197,9 @@ def _sn_conv(sd, seed, key, cout, cin, k=3, iters=40):
     fan_in = cin * k * k
     bound = 1.0 / math.sqrt(fan_in)
     w = (uniform01(seed, key + ".weight_orig", (cout, cin, k, k)) * 2 - 1) * bound
+    if key + ".weight_orig" in _SN_ROW_GAIN:
+        row, gain = _SN_ROW_GAIN[key + ".weight_orig"]
+        w[row] *= float(gain)
     sd[key + ".bias"] = _t((uniform01(seed, key + ".bias", (cout,)) * 2 - 1) * bound)
     sd[key + ".weight_orig"] = _t(w)
     wm = np.ascontiguousarray(w.reshape(cout, -1).astype(np.float32)).astype(np.float64)
@@ -212,9 +231,12 @@ def _resblock(sd, seed, key, cin, cout):
         sd[key + ".conv_out.bias"] = _t((uniform01(seed, key + ".conv_out.bias", (cout,)) * 2 - 1) * bound)
 
 
-def make_sr_state_dict(seed=1234):
-    """Keys of ``TSPSRNet`` (models/networks.py:328-409)."""
+def make_sr_state_dict(seed=1234, outliers=None):
+    """Keys of ``TSPSRNet`` (models/networks.py:328-409).  ``outliers``: see _apply_outliers; a ``*.weight_orig`` entry scales that output
+    row of a spectral-normalised conv before its u / v are power-iterated."""
     sd = {}
+    _SN_ROW_GAIN.clear()
+    _SN_ROW_GAIN.update({k: v for k, v in (outliers or {}).items() if k.endswith(".weight_orig")})
     D = 256
     _sn_conv(sd, seed, "conv_first_32.0", D // 4, 3)
     _sn_conv(sd, seed, "conv_first_16.0", D // 2, D // 4)
@@ -239,6 +261,11 @@ def make_sr_state_dict(seed=1234):
         _resblock(sd, seed, "conv_%s_fuse.0" % s, 2 * D, D)
     _sn_conv(sd, seed, "conv_32_to256.0", D, 512)
     _sn_conv(sd, seed, "conv_32_to256.2", D, D)
+    missing = [k for k in _SN_ROW_GAIN if k not in sd]
+    _apply_outliers(sd, outliers, skip=tuple(_SN_ROW_GAIN))
+    _SN_ROW_GAIN.clear()
+    if missing:
+        raise KeyError("outlier keys %s not in this state_dict" % missing)
     return sd
 
 

@@ -205,7 +205,7 @@ class _MixedStandIn:
     class _TG:
         precision, class_num = "fp32", 6736
 
-        def forward_nhwc(self, styles, labels, need_image=True, style_index=None, p64_out=None, p32_out=None):
+        def forward_nhwc(self, styles, labels, need_image=True, style_index=None, p64_out=None, p32_out=None, image_precision=None):
             v = styles[:, :1] + labels.float() * 1e-3
             return None, v.reshape(-1, 1, 1, 1).expand(-1, 2, 2, 4).contiguous(), (2 * v).reshape(-1, 1, 1, 1).expand(-1, 1, 1, 4).contiguous()
 
@@ -229,6 +229,7 @@ class _MixedStandIn:
         self.gan = type("G", (), {"TextGenerator": self._TG()})()
         self.precision, self.need_prior_image, self.check_finite, self._finite = "fp32", True, False, None
         self._checks = lambda: False
+        self._image_precision = lambda: None
         self._raise_if_not_finite = lambda: None
         self.run = MarconetPipeline._forward_mixed_widths.__get__(self)
 

@@ -524,6 +524,75 @@ def test_full_size_batch_sampled_against_the_oracle(nets, ckpts, precision):
         pipe.set_precision("fp32")
 
 
+@pytest.mark.parametrize("precision", ["fp16x2", "fp16x3"])
+def test_generator_chunks_are_bit_exact_and_meet_the_bar(nets, ckpts, precision):
+    """bench.py's batch-256 step is the only place where MarconetPipeline._core runs its glyph loop more than once
+    (4096 glyphs / glyph_chunk 1024).  Here 8 strips x 16 glyphs with glyph_chunk 48 → chunks of 48, 48 and 32 glyphs that start and end
+    in the middle of images: the SR output must equal the single-chunk run BIT FOR BIT (every conv gives the same bits whichever tile its
+    launch size selects; the priors land in slices of the all-glyph buffers), in the default configuration and without the prior
+    image (that variant in fp16x2), and three strips are recomputed by the oracle: <= 1e-3"""
+    from marconet_amd.pipeline import MarconetPipeline
+    B, n = 8, 16
+    lq = synth.make_lq(171, B, [512] * B)
+    labels = [synth.make_labels(180 + b, n) for b in range(B)]
+    locs = synth.make_locs([n] * B, [512] * B)
+    pipe = MarconetPipeline(*nets, precision=precision)
+    try:
+        whole = pipe.forward_batch(lq.to(DEV), labels, locs)
+        pipe.glyph_chunk = 48
+        chunked = pipe.forward_batch(lq.to(DEV), labels, locs)
+        pipe.need_prior_image = False
+        chunked_noimg = pipe.forward_batch(lq.to(DEV), labels, locs)
+        pipe.glyph_chunk = 1024
+        whole_noimg = pipe.forward_batch(lq.to(DEV), labels, locs)
+        assert torch.equal(whole, chunked) and torch.equal(whole, chunked_noimg) and torch.equal(whole, whole_noimg)
+        worst = 0.0
+        for b in (0, 2, 7):                     # strip 2 straddles chunks 0 / 1 (glyphs 32-47 | 48-63), strip 7 is in the short last chunk
+            r = O.end_to_end(ckpts[0], ckpts[1], ckpts[2], lq[b:b + 1], [labels[b]], locs[b:b + 1])
+            worst = max(worst, _err(chunked_noimg[b:b + 1], r["sr"]))
+        _note("sr.%s.chunked_generator_8x16_chunk48.sampled3.maxabs" % precision, worst)
+        assert worst <= TOL
+    finally:
+        pipe.set_precision("fp32")
+
+
+@pytest.mark.parametrize("precision", ["fp16x2", "fp16x3"])
+def test_prior_image_precision_leaves_sr_bits_unchanged(nets, ckpts, precision):
+    """the batched driver runs the generator levels behind the two prior levels (they feed only the structure image it never returns,
+    models/networks.py:161-164) in plain fp16: priors and SR output must not change by a bit; the image itself stays a finite,
+    loosely bounded picture (reported), and TSPGAN.forward — the reference call form that RETURNS the image — keeps the mode's arithmetic"""
+    from marconet_amd.pipeline import MarconetPipeline
+    counts = [5, 3, 16]
+    lq = synth.make_lq(191, 3, [512, 300, 512])
+    labels = [synth.make_labels(192 + b, c) for b, c in enumerate(counts)]
+    locs = synth.make_locs(counts, [512, 300, 512], max_glyphs=16)
+    pipe = MarconetPipeline(*nets, precision=precision)
+    try:
+        assert pipe._image_precision() == "fp16"
+        y_auto = pipe.forward_batch(lq.to(DEV), labels, locs)
+        pipe.prior_image_precision = None
+        assert pipe._image_precision() is None
+        y_mode = pipe.forward_batch(lq.to(DEV), labels, locs)
+        assert torch.equal(y_auto, y_mode) and torch.isfinite(y_auto).all()
+        tg = nets[1].TextGenerator
+        tg.precision = precision
+        w = nets[0](lq.to(DEV))[2]
+        lab = labels[2].to(DEV)
+        st = w[2:3].repeat(lab.shape[0], 1).contiguous()
+        img16, a16, c16 = tg.forward_nhwc(st, lab, image_precision="fp16")
+        img, a, c = tg.forward_nhwc(st, lab)
+        from marconet_amd import ops
+        assert torch.equal(ops.convert(a16, torch.float32), ops.convert(a, torch.float32)) and torch.equal(ops.convert(c16, torch.float32), ops.convert(c, torch.float32))
+        with torch.no_grad():
+            ref = O.tspgan_forward(ckpts[1], O.encoder_forward(ckpts[0], lq[2:3])[2].repeat(lab.shape[0], 1), labels[2])[0]
+        e_mode, e16 = _err(ops.nhwc_to_nchw(img, c=3), ref), _err(ops.nhwc_to_nchw(img16, c=3), ref)
+        _note("gan.%s.image.maxabs" % precision, e_mode)
+        _note("gan.%s.image_levels_in_fp16.image.maxabs" % precision, e16)
+        assert e_mode <= TOL and e16 <= 2.5e-2 and torch.isfinite(img16).all()
+    finally:
+        pipe.set_precision("fp32")
+
+
 def test_forward_batch_vs_oracle_on_bench_shaped_strips(nets, ckpts):
     """the batched driver (what bench.py times) against the CPU oracle on 4 strips of the bench shape — full 512-px width,
     ragged glyph counts up to the bench's 16 per image — in the fp32 parity mode: <= 1e-3, indices bit-exact"""

@@ -102,3 +102,60 @@ def test_near_tie_logits(prec):
     assert err <= 3e-5
     assert torch.equal(idx[safe], top.indices[..., 0][safe])
     assert ((idx == top.indices[..., 0]) | (idx == top.indices[..., 1])).all()
+
+
+# ---- outlier channels inside a 32-channel storage block -------------------------------------------------------
+# The fp16+8 format shares ONE E8M0 scale per (pixel, 32-channel block): an outlier channel takes the block's scale and the other 31
+# channels' lo bytes lose resolution (e4m3 keeps 4 significant bits down to 2^-6 of the block scale's range, i.e. over a factor of
+# ~3e4 between the largest and the smallest channel).  Trained StyleGAN-type weights produce such channels; the synthetic
+# checkpoints do not, so they are planted here: a GroupNorm gain (its output feeds a conv directly), a row of a spectral-normalised
+# conv (its output channel dominates the next conv's input block) and a modulation bias of the generator (one modulated input channel).
+OUTLIERS = {
+    # name: (generator outliers, SR-net outliers, bar for fp16x2 / None = report only)
+    "x100": ({"TextGenerator.convs.5.conv.modulation.bias": (9, 100.0)},
+             {"conv_up.3.norm1.weight": (37, 100.0), "conv_64_fuse.0.norm2.weight": (200, 100.0),
+              "conv_body_32.0.weight_orig": (17, 100.0), "conv_64_scale.0.weight_orig": (5, 100.0)}, TOL),
+    "x1000_trunk_gn": ({}, {"conv_up.3.norm1.weight": (37, 1000.0)}, TOL),
+    # CPU emulation of the arithmetic (tools/precision_plan.py machinery): fp16x2 1.4e-3, fp16x3 2.7e-4 — the network itself is 10x
+    # worse conditioned with this gain (fp16x3 is normally at 2.7e-5); fp16x2 is reported, fp16x3 must hold the bar
+    "x1000_fuse64_gn": ({}, {"conv_64_fuse.0.norm2.weight": (200, 1000.0)}, None),
+}
+
+
+@functools.lru_cache(maxsize=None)
+def _outlier_case(name):
+    from marconet_amd import synthetic
+    g, s, _ = OUTLIERS[name]
+    sdg = synthetic.make_gan_state_dict(outliers=g)
+    sds = synthetic.make_sr_state_dict(outliers=s)
+    return sdg, sds
+
+
+@pytest.mark.parametrize("name", list(OUTLIERS))
+def test_outlier_channel_inside_a_storage_block(name, ckpts):
+    """one channel 1e2 / 1e3 times larger than its 31 block neighbours, planted in mid-network activations: SR deviation of the
+    fp16x2 and fp16x3 modes against the CPU oracle on the same weights"""
+    from marconet_amd import networks
+    from marconet_amd.pipeline import MarconetPipeline
+    sdg, sds = _outlier_case(name)
+    bar = OUTLIERS[name][2]
+    enc, gan, sr = networks.TextContextEncoderV2(), networks.TSPGAN(), networks.TSPSRNet()
+    enc.load_state_dict(ckpts[0]); gan.load_state_dict(sdg); sr.load_state_dict(sds)
+    n = 8
+    lq = synth.make_lq(77, 1, [512])
+    labels, locs = [synth.make_labels(78, n)], synth.make_locs([n], [512])
+    ref = O.end_to_end(ckpts[0], sdg, sds, lq, labels, locs)["sr"]
+    pipe = MarconetPipeline(enc.eval().to(DEV), gan.eval().to(DEV), sr.eval().to(DEV), precision="fp32")
+    errs = {}
+    for prec in ("fp32", "fp16x3", "fp16x2"):
+        pipe.set_precision(prec)
+        y = pipe.forward_batch(lq.to(DEV), labels, locs)
+        assert torch.isfinite(y).all()
+        errs[prec] = _cmp("outlier %s %s" % (name, prec), y, ref)
+    assert errs["fp32"] <= TOL and errs["fp16x3"] <= TOL
+    if bar is not None:
+        assert errs["fp16x2"] <= bar
+    else:
+        # report only: the deviation must still be the format's resolution on a badly conditioned net (a small multiple of fp16x3's),
+        # not a breakdown
+        assert errs["fp16x2"] <= 1e-2 and errs["fp16x2"] <= 12 * max(errs["fp16x3"], 1e-5)
