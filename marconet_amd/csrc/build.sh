@@ -4,6 +4,9 @@ set -euo pipefail
 HERE="$(cd "$(dirname "${BASH_SOURCE[0]}")" && pwd)"
 OUT="$HERE/../lib"
 mkdir -p "$OUT"
+# MNET_CLEAN=1: throw the objects away first, so that the build PROVES a compile (the default is incremental on mtimes: a tree
+# that already holds fresh objects only re-links)
+if [ "${MNET_CLEAN:-0}" != "0" ]; then rm -f "$OUT"/*.o "$OUT"/*.o.tmp "$OUT"/libmarconet_hip.so; echo "[build] MNET_CLEAN: objects removed, full compile"; fi
 HIPCC="${HIPCC:-/opt/rocm/bin/hipcc}"
 PIDS=()
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-function"

@@ -20,6 +20,7 @@
 //    tensor and channel offset are wave-uniform scalars advanced incrementally — no integer division in the loop.
 //  * the epilogue runs as whole-register-set passes behind wave-uniform branches (a per-element `switch (act)` compiled
 //    to ~1000 scalar branches / 100 KB of code and cost 10 us per tile).
+#include <type_traits>
 #include "conv_dma_common.h"
 
 // MF = 16: v_mfma_f32_16x16x32_f16 — production;
@@ -39,18 +40,31 @@
 //     x*w = hi*hi on v_mfma_f32_32x32x16_f16 + (w_lo8*x_hi8 + w_hi8*x_lo8) as ONE v_mfma_scale_f32_32x32x64_f8f6f4 (2x rate, the
 //     block scales s_w * s_x * 2^-11 applied by the instruction): 2 MFMA units per product instead of 3.  x_hi8 is converted from
 //     the f16 fragments the lane already holds (v_cvt_scalef32_pk_fp8_f16).
-template <int BC, int BP, int WC, int WP, int STAGES, int MF = 16, int DBG = 0, bool X3 = false, bool SPREAD = false, bool PIPE = false, bool MX = false>
+// SWP (with MX, 8 waves, 2 stages; round 4): the slab loop SOFTWARE-PIPELINED across the slab barrier.  Measured on the lock-step loop
+//     (tools/slab_phases.py, profiles/r4c_slab_phases*.txt): of ~3350 cycles per slab the matrix pipe works 2048 — the younger wave of a SIMD spends
+//     1600 cycles on the 16 f16 MFMAs (LDS latency after the barrier, the pipe shared with its partner), 830 issuing the 8 DMA pieces in one
+//     block and 680 on conversions + 8 scaled MFMAs, while its partner waits 900 cycles at the barrier.  Here a slab iteration is
+//         barrier(s) | LDS reads of slab s's f16 operands | 8 scaled MFMAs of slab s-1, ONE DMA piece of slab s+1 behind each (64 pipe cycles
+//         cover a piece's issue) | 16 f16 MFMAs of slab s with the fp8-side LDS reads and the fp8 conversions of slab s between them
+//     so that the LDS latency sits under the previous slab's scaled MFMAs, the DMA pieces get the whole slab to land, and no phase is without
+//     MFMAs.  Per output the order stays f16 k-step 0, f16 k-step 1, scaled fp8 of slab 0, then slab 1, ...: the bytes equal the other fp16+8 tiles'.
+//     LDS hazards: slab s-1's stage is last read (fp8-side operands) during the f16 MFMAs of iteration s-1, before barrier(s); the DMA of slab
+//     s+1 into that stage starts after barrier(s).
+template <int BC, int BP, int WC, int WP, int STAGES, int MF = 16, int DBG = 0, bool X3 = false, bool SPREAD = false, bool PIPE = false, bool MX = false, bool SWP = false>
 __global__ void __launch_bounds__(WC * WP * 64, WC * WP / 4) conv_dma_kernel(const ConvArgs p) {
     constexpr int NW = WC * WP;                          // waves per workgroup (8 or 16)
     constexpr int FC = BC / WC / 16, FP = BP / WP / 16;
-    constexpr int WJ = BC / (8 * NW), XJ = BP / (8 * NW); // DMA instructions per wave per slab (weights / activations)
+    constexpr int NWI = NW;                              // waves that issue DMA: all of them (an asymmetric form — the older wave of every SIMD issuing all
+                                                         // the pieces — measured -27 %, a one-wave-per-SIMD 128x128 form spilled 450 registers: DESIGN.md §3.1e)
+    constexpr int WJ = BC / (8 * NWI), XJ = BP / (8 * NWI); // DMA instructions per wave per slab (weights / activations)
     constexpr int NDMA = WJ + XJ;
     constexpr int STAGE = (BC + BP) * 128;
     constexpr unsigned OOB = 0x80000000u;                // beyond every num_records used below
     static_assert(NW == 8 || NW == 16, "8 or 16 waves");
     static_assert(!MX || (X3 && MF == 32), "MX: 4-byte storage, 32x32 MFMAs");
-    static_assert(!SPREAD || (STAGES == 2 && (MF == 16 || X3) && DBG == 0), "SPREAD: production 2-stage tiles only");
-    static_assert(WJ >= 1 && XJ >= 1 && WJ * 8 * NW == BC && XJ * 8 * NW == BP, "tile / wave-count mismatch");
+    static_assert(!SWP || (MX && NW == 8 && STAGES == 2 && (DBG == 0 || DBG == 6) && (FC / 2) * (FP / 2) <= 16 && NDMA <= 16), "SWP: fp16+8, 2 stages, <= 16 accumulator blocks per wave");
+    static_assert(!SPREAD || (STAGES == 2 && (MF == 16 || X3) && (DBG == 0 || DBG == 6)), "SPREAD: production 2-stage tiles only");
+    static_assert(WJ >= 1 && XJ >= 1 && WJ * 8 * NWI == BC && XJ * 8 * NWI == BP, "tile / wave-count mismatch");
     static_assert(STAGES == 2 || ((STAGES == 3 || STAGES == 4) && NDMA >= 4 && NDMA <= 6), "vmcnt immediates below cover 4-6 DMAs per slab, up to 3 slabs in flight");
     static_assert((BC / WC) % 64 == 0 && (BP / WP) % 32 == 0, "the channel permutation works on 64-channel blocks of a wave tile");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -86,7 +100,7 @@ __global__ void __launch_bounds__(WC * WP * 64, WC * WP / 4) conv_dma_kernel(con
     // 16-byte slot inside the 128-byte slab row, XOR-swizzled on the source side.  Row (wave + NW j)*8 + rg → (row >> 1) & 7 =
     // 4*(wave & 1) + (rg >> 1) for every j (NW is even): ONE value per lane, not one per piece
     const unsigned lcb = (unsigned)((pc ^ (((wave & 1) << 2) + (rg >> 1))) << 4);
-    static_assert(NW % 2 == 0, "lcb is piece-independent only for an even wave count");
+    static_assert(NWI % 2 == 0, "lcb is piece-independent only for an even issuing-wave count");
     int cur_c = 0, cur_s = 0, cur_tap = 0, cur_tpx = 0, cur_k = 0;   // wave-uniform k-slab cursor
     const long long img0 = (long long)p.h * p.w * p.c0 * 2, img1 = (long long)p.h * p.w * p.c1 * 2;
 
@@ -108,7 +122,7 @@ __global__ void __launch_bounds__(WC * WP * 64, WC * WP / 4) conv_dma_kernel(con
         // Weight rows are permuted on their way into LDS (free: the DMA source address is per lane), see dma_weight_channel
 #pragma unroll
         for (int j = 0; j < WJ; ++j) {
-            const int row = (wave + NW * j) * 8 + rg;
+            const int row = (wave + NWI * j) * 8 + rg;
             const int ch = MX ? dma_weight_channel_mx(row) : dma_weight_channel<MF>(row);
             const int lc = pc ^ ((row >> 1) & 7);
             woff[j] = (co0 + ch < p.cout) ? (unsigned)(ch * p.K * 2 + lc * 16) : OOB;
@@ -117,7 +131,7 @@ __global__ void __launch_bounds__(WC * WP * 64, WC * WP / 4) conv_dma_kernel(con
         // kh*kw <= 32 on this path
 #pragma unroll
         for (int j = 0; j < XJ; ++j) {
-            const int row = (wave + NW * j) * 8 + rg;
+            const int row = (wave + NWI * j) * 8 + rg;
             const int pix = pix0 + row;
             xpx[j] = 0; xmask[j] = 0;
             if (pix < p.npix) {
@@ -374,6 +388,20 @@ __global__ void __launch_bounds__(WC * WP * 64, WC * WP / 4) conv_dma_kernel(con
                     acc32[fa][fb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bitcast<f16x8>(a[k2][fa]), bitcast<f16x8>(bh[k2][fb]), acc32[fa][fb], 0, 0, 0);
     };
 
+    // DBG == 6 (DIAGNOSTIC, fp16+8 id 14; tools/slab_phases.py): shader cycles a wave spends in each phase of a hot slab, summed over the launch —
+    //   0: LDS reads + the 16 f16 MFMAs   1: issue of the next slab's DMA pieces   2: fp8 conversions + the 8 scaled MFMAs
+    //   3: s_waitcnt vmcnt(0)             4: s_barrier
+    // (s_memtime needs lgkmcnt(0): each stamp also drains the wave's LDS reads — the stamps sit where the data is needed anyway)
+    unsigned ph_sum[5] = {0u, 0u, 0u, 0u, 0u}, ph_prev = 0u, ph_slabs = 0u;
+    auto ph_stamp = [&](int i) __attribute__((always_inline)) {
+        if constexpr (DBG == 6) {
+            __builtin_amdgcn_sched_barrier(0);
+            const unsigned t = (unsigned)__builtin_readcyclecounter();
+            if (i >= 0) ph_sum[i] += t - ph_prev;
+            ph_prev = t;
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
     // fp16+8 slab (see the MX note above the kernel)
     int mx_sa[MF == 32 ? FC / 2 : 1];                      // per weight fragment: E8M0 byte of s_w * 2^-11 for this lane's row (constant over k)
     // PIPE: every LDS read of the slab is requested in program order up front and placed by scheduling hints — the f16 operands before
@@ -426,7 +454,9 @@ __global__ void __launch_bounds__(WC * WP * 64, WC * WP / 4) conv_dma_kernel(con
             }
             if constexpr (NM > NF8) __builtin_amdgcn_sched_group_barrier(0x008, NM - NF8, 0);
         }
+        ph_stamp(0);
         between();
+        ph_stamp(1);
         // x_hi8 of this lane's 16 channels (the two f16 chunks it holds): e4m3(hi / s_x)
 #pragma unroll
         for (int f = 0; f < FB; ++f) {
@@ -455,6 +485,7 @@ __global__ void __launch_bounds__(WC * WP * 64, WC * WP / 4) conv_dma_kernel(con
 #pragma unroll
             for (int fb = 0; fb < FB; ++fb)
                 acc32[fa][fb] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a8[fa], b8[fb], acc32[fa][fb], 0, 0, 0, mx_sa[fa], 0, eb[fb]);
+        ph_stamp(2);
     };
     auto compute_split = [&](int stage, auto&& between) __attribute__((always_inline)) {
         if constexpr (MX) compute_mx(stage, between);
@@ -468,6 +499,240 @@ __global__ void __launch_bounds__(WC * WP * 64, WC * WP / 4) conv_dma_kernel(con
         else { if constexpr (NDMA == 6) VMCNT(6); else if constexpr (NDMA == 5) VMCNT(5); else VMCNT(4); }
     };
 
+
+    if constexpr (SWP) {
+        constexpr int FA = FC / 2, FB = FP / 2;
+        const int l32 = lane & 31, h = lane >> 5;
+        // slab issue in pieces (the same addresses as issue_w / issue_x): begin → the stream has another slab (crossing into the next tile if needed)
+        auto sw_begin = [&]() __attribute__((always_inline)) -> bool {
+            if (i_kt == nk) {
+                i_kt = 0; i_v += G;
+                i_live = i_v < ntiles;
+                if (i_live) setup(i_v);
+            }
+            return i_live;
+        };
+        // a slab's pieces are straight-line code (no branch inside the scaled-MFMA group: LLVM sinks the MFMAs past control flow): the wave-uniform
+        // parts of the addresses — descriptors, k offset, tap bit, concat source — are formed once per slab by sw_slab(), and a slab that does not
+        // exist (end of the stream) is issued with out-of-range offsets (zeros into a stage nobody reads)
+        __amdgpu_buffer_rsrc_t sl_rW, sl_rX;
+        unsigned sl_kb = 0, sl_tap = 0, sl_cb = 0, sl_uni = 0, sl_dead = 0;
+        auto sw_slab = [&](bool more) __attribute__((always_inline)) {
+            const bool second = cur_c >= p.c0;                           // wave-uniform: second concat source
+            sl_rW = __builtin_amdgcn_make_buffer_rsrc((void*)uni64(bW), 0, __builtin_amdgcn_readfirstlane(nW), 0x00020000);
+            sl_rX = __builtin_amdgcn_make_buffer_rsrc((void*)uni64(second ? bX1 : bX0), 0, __builtin_amdgcn_readfirstlane(second ? nX1 : nX0), 0x00020000);
+            sl_kb = (unsigned)(cur_tap * p.cin + cur_c) * 2u;
+            sl_tap = (unsigned)cur_tap;
+            sl_cb = (unsigned)(second ? p.c1 : p.c0) * 2u;
+            sl_uni = (unsigned)(cur_tpx * (int)sl_cb + (second ? cur_c - p.c0 : cur_c) * 2) + lcb;
+            sl_dead = more ? 0u : OOB;
+        };
+        auto sw_piece = [&](int idx) __attribute__((always_inline)) {
+            unsigned char* sw_ = smem + i_stage * STAGE;
+            if (idx < WJ) {
+                const unsigned vo = (woff[idx] + sl_kb) | sl_dead;       // (an OOB row keeps bit 31 through the addition: sl_kb < 2^31)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(sl_rW, (lds_void*)(sw_ + (wave + NWI * idx) * 1024), 16, vo, 0, 0, 0);
+            } else {
+                const int j = idx - WJ;
+                unsigned char* sx_ = sw_ + BC * 128;
+                // branch-free and select-free (a `cond ? address : OOB` here is compiled to an exec-masked region, i.e. a basic-block split inside the
+                // MFMA group): an invalid tap ORs bit 31 into the offset, which puts it beyond every num_records
+                const unsigned inval = (((xmask[j] >> sl_tap) & 1u) - 1u) & OOB;
+                const unsigned vo = ((unsigned)__mul24((int)xpx[j], (int)sl_cb) + sl_uni) | inval | sl_dead;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(sl_rX, (lds_void*)(sx_ + (wave + NWI * j) * 1024), 16, vo, 0, 0, 0);
+            }
+        };
+        auto sw_end = [&]() __attribute__((always_inline)) {
+            cur_k += 64; ++cur_tap;
+            if (++cur_s == p.kw) { cur_s = 0; cur_tpx += p.w - (p.kw - 1); } else { ++cur_tpx; }
+            if (cur_tap == p.kh * p.kw) { cur_tap = 0; cur_s = 0; cur_tpx = 0; cur_c += 64; }
+            i_stage ^= 1;
+            ++i_kt;
+        };
+        auto load_scales = [&](int v) __attribute__((always_inline)) {   // E8M0 bytes of the weight scales of tile v (see the lock-step loop)
+            int co0, pix0;
+            tile_coords(v, co0, pix0);
+            const unsigned char* wexp = reinterpret_cast<const unsigned char*>(p.wgt) + (size_t)p.cout * p.K * 2;
+#pragma unroll
+            for (int f = 0; f < FA; ++f) {
+                const int ch = co0 + dma_weight_channel_mx(wc * (BC / WC) + f * 32 + l32);
+                mx_sa[f] = ch < p.cout ? (int)wexp[ch] : 0;
+            }
+            // the loads must have RETURNED here, in the compiler's book-keeping too: left pending across the loop's back edge they would put an
+            // `s_waitcnt vmcnt(0)` in front of the scaled MFMAs of EVERY slab, i.e. right behind the DMA pieces
+#pragma unroll
+            for (int f = 0; f < FA; ++f) asm volatile("" : "+v"(mx_sa[f]));
+        };
+        auto zero_acc = [&]() __attribute__((always_inline)) {
+#pragma unroll
+            for (int a = 0; a < FA; ++a)
+#pragma unroll
+                for (int b = 0; b < FB; ++b)
+#pragma unroll
+                    for (int q = 0; q < 16; ++q) acc32[a][b][q] = 0.f;
+        };
+        auto bar = [&]() __attribute__((always_inline)) {
+            asm volatile("" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+        };
+        // per-lane LDS offsets of the operand fragments (swz_dma(row, chunk) of fragment 0; fragment f is f * 32 rows = f * 4096 bytes further; the
+        // other chunks of a row are XORs on the ADDRESS: the swizzle is an XOR of the chunk index, rows are 128-byte aligned and fragment rows keep (row >> 1) & 7)
+        const unsigned pa0 = (unsigned)swz_dma(wc * (BC / WC) + l32, h), pa8 = (unsigned)swz_dma(wc * (BC / WC) + l32, 4 + 2 * h);
+        const unsigned pb0 = (unsigned)swz_dma(wp * (BP / WP) + l32, h), pbe = (unsigned)swz_dma(wp * (BP / WP) + l32, 6);
+
+        u32x4 a[2][FA], bh[2][FB];                                       // f16 operands of the slab whose f16 MFMAs run in this iteration
+        i32x8 a8[FA], b8[FB];                                            // fp8-side operands, carried to the NEXT iteration's scaled MFMAs
+        int eb[FB], ebn[FB];                                             // E8M0 of s_x: of the carried slab / of the slab being read
+        // ---- the three parts of an iteration
+        auto front = [&](unsigned so) __attribute__((always_inline)) {   // LDS reads of slab s's first f16 k-step and its scale bytes (the second
+            const unsigned aa = pa0 + so, ba = pb0 + so + BC * 128u, bea = pbe + so + BC * 128u;   // k-step's operands would not fit beside the carried fp8 operands)
+#pragma unroll
+            for (int f = 0; f < FA; ++f) a[0][f] = *reinterpret_cast<const u32x4*>(smem + (aa + f * 4096u));                  // chunk h
+#pragma unroll
+            for (int f = 0; f < FB; ++f) bh[0][f] = *reinterpret_cast<const u32x4*>(smem + (ba + f * 4096u));
+#pragma unroll
+            for (int f = 0; f < FB; ++f) ebn[f] = *(smem + (bea + f * 4096u));                                                 // chunk 6, byte 0
+        };
+        auto scaled_prev = [&](auto with_pieces) __attribute__((always_inline)) {   // 8 scaled MFMAs of the carried slab, one DMA piece of the next slab behind each
+            constexpr bool pieces = decltype(with_pieces)::value;
+#pragma unroll
+            for (int fa = 0; fa < FA; ++fa)
+#pragma unroll
+                for (int fb = 0; fb < FB; ++fb) {
+                    acc32[fa][fb] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a8[fa], b8[fb], acc32[fa][fb], 0, 0, 0, mx_sa[fa], 0, eb[fb]);
+                    if (pieces) asm volatile("" : "+v"(acc32[fa][fb]));  // pins the MFMA in front of its piece at the IR level (a pure intrinsic is otherwise sunk to its use)
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (pieces) {                                        // compile-time
+                        const int i = fa * FB + fb;
+                        if (i < NDMA) sw_piece(i);
+                        if (i == FA * FB - 1) {
+#pragma unroll
+                            for (int idx = FA * FB; idx < NDMA; ++idx) sw_piece(idx);
+                        }
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+        };
+        auto f16_part = [&](unsigned so) __attribute__((always_inline)) {   // 2 FA FB f16 MFMAs of slab s; its fp8-side reads and conversions between them
+            const unsigned aa = pa0 + so, a8a = pa8 + so, ba = pb0 + so + BC * 128u;
+            // up front: the second k-step's activation operands and the activations' lo bytes (the second k-step's weight fragments follow the
+            // first k-step's out of the registers: fragment fa is read behind the last MFMA that uses a[0][fa])
+#pragma unroll
+            for (int f = 0; f < FB; ++f) bh[1][f] = *reinterpret_cast<const u32x4*>(smem + ((ba ^ 32u) + f * 4096u));         // chunk 2 + h
+#pragma unroll
+            for (int f = 0; f < FB; ++f) {
+                eb[f] = ebn[f];
+                const u32x4 lo8 = *reinterpret_cast<const u32x4*>(smem + ((ba ^ 64u) + f * 4096u));                           // chunk 4 + h
+                b8[f][4] = (int)lo8[0]; b8[f][5] = (int)lo8[1]; b8[f][6] = (int)lo8[2]; b8[f][7] = (int)lo8[3];
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            // explicit placement (program order pinned by fences: scheduling hints did not hold the reads in front): behind MFMA i
+            //   i < 2 FA      : one fp8-side weight read (lo8 / hi8 chunk of fragment i / 2) into the registers the scaled MFMAs have just released
+            //   i < 4 FB      : one x_hi8 conversion group (2 v_cvt_scalef32_pk_fp8_f16 of 16 channels' halves; first k-step first)
+            constexpr int NM = 2 * FA * FB;
+#pragma unroll
+            for (int i = 0; i < NM; ++i) {
+                const int k2 = i / (FA * FB), fa = (i % (FA * FB)) / FB, fb = i % FB;
+                acc32[fa][fb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bitcast<f16x8>(a[k2][fa]), bitcast<f16x8>(bh[k2][fb]), acc32[fa][fb], 0, 0, 0);
+                if (i < 2 * FA || i < 4 * FB) {
+                    asm volatile("" : "+v"(acc32[fa][fb]));
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (i < 2 * FA) {
+                        const int f = i >> 1;
+                        const u32x4 q = *reinterpret_cast<const u32x4*>(smem + (((i & 1) ? (a8a ^ 16u) : a8a) + f * 4096u));       // chunk 4 + 2 h / 5 + 2 h
+                        const int o = (i & 1) * 4;
+                        a8[f][o] = (int)q[0]; a8[f][o + 1] = (int)q[1]; a8[f][o + 2] = (int)q[2]; a8[f][o + 3] = (int)q[3];
+                    }
+                    if (i < FA * FB && fb == FB - 1)
+                        a[1][fa] = *reinterpret_cast<const u32x4*>(smem + ((aa ^ 32u) + fa * 4096u));                          // chunk 2 + h
+                    if (i < 4 * FB) {
+                        const int kk = i / (2 * FB), f = (i >> 1) % FB, d = i & 1;
+                        const float sc = __builtin_bit_cast(float, (unsigned)ebn[f] << 23);
+                        s16x2 r = {0, 0};
+                        r = __builtin_amdgcn_cvt_scalef32_pk_fp8_f16(r, bitcast<f16x2>(bh[kk][f][2 * d]), sc, false);
+                        r = __builtin_amdgcn_cvt_scalef32_pk_fp8_f16(r, bitcast<f16x2>(bh[kk][f][2 * d + 1]), sc, true);
+                        b8[f][2 * kk + d] = bitcast<int>(r);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+        };
+
+        setup(i_v);
+        {                                                                // slab 0 (a workgroup always has a tile)
+            const bool more = sw_begin();
+            sw_slab(more);
+#pragma unroll
+            for (int idx = 0; idx < NDMA; ++idx) sw_piece(idx);
+            if (more) sw_end();
+        }
+        int c_v = blockIdx.x, c_kt = 0;                                  // tile / slab index inside it of the slab whose f16 MFMAs run in the iteration
+        load_scales(c_v);
+        zero_acc();
+        const int total = ((ntiles - (int)blockIdx.x + G - 1) / G) * nk; // slabs in this workgroup's stream
+        // ---- iteration 0: nothing carried yet
+        VMCNT(0);
+        bar();
+        front(0u);
+        __builtin_amdgcn_sched_barrier(0);
+        {
+            const bool more = sw_begin();
+            sw_slab(more);
+#pragma unroll
+            for (int idx = 0; idx < NDMA; ++idx) sw_piece(idx);
+            if (more) sw_end();
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        f16_part(0u);
+        c_kt = 1;
+        ph_stamp(-1);
+        for (int s = 1; s < total; ++s) {
+            VMCNT(0);                                                    // this wave's pieces of slab s (and the previous epilogue's stores) have landed ...
+            ph_stamp(3);                                                 // (DBG == 6 only — phases: 1 front reads + scaled MFMAs + pieces, 2 f16 part, 3 vmcnt(0), 4 barrier)
+            bar();                                                       // ... everyone's; nobody reads the stage of slab s-1 any more
+            ph_stamp(4);
+            ++ph_slabs;
+            const unsigned so = (unsigned)(s & 1) * (unsigned)STAGE;
+            front(so);
+            __builtin_amdgcn_sched_barrier(0);
+            const bool more = sw_begin();
+            sw_slab(more);
+            __builtin_amdgcn_sched_barrier(0);
+            scaled_prev(std::true_type{});
+            ph_stamp(1);
+            if (more) sw_end();
+            if (c_kt == nk) {                                            // slab s-1 closed its tile: epilogue, then the next tile's scales and a clean accumulator
+                int co0, pix0;
+                tile_coords(c_v, co0, pix0);
+                dma_epilogue_mx<BC, BP, WC, WP, FC, FP>(p, acc32, co0, pix0, wc, wp, lane);
+                c_kt = 0; c_v += G;
+                if (p.tilesC > 1) load_scales(c_v);                      // (one channel tile: every tile has the same scales)
+                zero_acc();
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            f16_part(so);
+            ph_stamp(2);
+            ++c_kt;
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        scaled_prev(std::false_type{});                                  // the last slab's scaled MFMAs
+        {
+            int co0, pix0;
+            tile_coords(c_v, co0, pix0);
+            dma_epilogue_mx<BC, BP, WC, WP, FC, FP>(p, acc32, co0, pix0, wc, wp, lane);
+        }
+        if constexpr (DBG == 6) {       // DIAGNOSTIC: phase sums of this wave over the first bytes of the output (32 bytes per wave)
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            if (lane == 0) {
+                unsigned* o = reinterpret_cast<unsigned*>(p.y) + ((size_t)blockIdx.x * NW + wave) * 8;
+                o[0] = 0x5157a3b6u; o[1] = ph_slabs; o[2] = ph_sum[0]; o[3] = ph_sum[1]; o[4] = ph_sum[2]; o[5] = ph_sum[3]; o[6] = ph_sum[4];
+                o[7] = __builtin_amdgcn_s_getreg((31 << 11) | 4);
+            }
+        }
+        return;
+    }
     // ---- prime the ring (STAGES-1 slabs ahead), then walk this workgroup's tiles
     setup(i_v);
     int inflight = 0;
@@ -508,13 +773,16 @@ __global__ void __launch_bounds__(WC * WP * 64, WC * WP / 4) conv_dma_kernel(con
 
         // hot iterations: the slab issued stays inside this tile (same loop body as a non-persistent kernel)
         const int hot = nk - (STAGES - 1) > 0 ? nk - (STAGES - 1) : 0;
+        ph_stamp(-1);
         for (int kt = 0; kt < hot; ++kt) {
             // the oldest slab in flight must have landed (this wave's share; the barrier extends it to everyone's)
             if (STAGES > 2 && !drain) wait_keep(STAGES - 2);
             else VMCNT(0);
             drain = false;
+            if (kt > 0) ph_stamp(3);
             __builtin_amdgcn_s_barrier();                // ... and every wave is done reading the stage refilled next
             asm volatile("" ::: "memory");
+            if (kt > 0) { ph_stamp(4); ++ph_slabs; } else ph_stamp(-1);
             if constexpr (SPREAD) {
                 // the DMA pieces of the next slab ride between the multiplies of this one (sched barriers pin the placement)
                 auto adv = [&]() __attribute__((always_inline)) { i_stage = i_stage == STAGES - 1 ? 0 : i_stage + 1; ++i_kt; };
@@ -571,12 +839,21 @@ __global__ void __launch_bounds__(WC * WP * 64, WC * WP / 4) conv_dma_kernel(con
             }
         }
     }
+    if constexpr (DBG == 6) {           // DIAGNOSTIC: phase sums of this wave over the first bytes of the output (32 bytes per wave)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if (lane == 0) {
+            unsigned* o = reinterpret_cast<unsigned*>(p.y) + ((size_t)blockIdx.x * NW + wave) * 8;
+            o[0] = 0x5157a3b6u; o[1] = ph_slabs; o[2] = ph_sum[0]; o[3] = ph_sum[1]; o[4] = ph_sum[2]; o[5] = ph_sum[3]; o[6] = ph_sum[4];
+            o[7] = __builtin_amdgcn_s_getreg((31 << 11) | 4);        // HW_ID (SIMD / CU of this wave)
+        }
+    }
 }
 
-template <int BC, int BP, int WC, int WP, int STAGES, int MF = 16, int DBG = 0, bool X3 = false, bool SPREAD = false, bool PIPE = false, bool MX = false>
+template <int BC, int BP, int WC, int WP, int STAGES, int MF = 16, int DBG = 0, bool X3 = false, bool SPREAD = false, bool PIPE = false, bool MX = false, bool SWP = false>
 static int launch_dma_cfg(const ConvArgs& a, hipStream_t st) {
     constexpr int LDS = STAGES * (BC + BP) * 128;
-    auto kern = conv_dma_kernel<BC, BP, WC, WP, STAGES, MF, DBG, X3, SPREAD, PIPE, MX>;
+    auto kern = conv_dma_kernel<BC, BP, WC, WP, STAGES, MF, DBG, X3, SPREAD, PIPE, MX, SWP>;
     static thread_local DeviceOnce attr_once;      // per instantiation, per thread, per device
     if (!attr_once.done()) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
@@ -619,6 +896,15 @@ static int launch_dma_id(int id, const ConvArgs& a, hipStream_t st) {
             case 11: return launch_dma_cfg<256, 256, 2, 4, 2, 32, 0, true, true, true, true>(a, st);          // id 6 + LDS reads placed by scheduling hints
             case 12: return launch_dma_cfg<128, 512, 1, 8, 2, 32, 0, true, true, true, true>(a, st);          // id 8, same
             case 13: return launch_dma_cfg<64, 512, 1, 8, 2, 32, 0, true, true, true, true>(a, st);           // id 5, same
+            case 15: return launch_dma_cfg<256, 256, 2, 4, 2, 32, 0, true, false, false, true, true>(a, st);       // id 6 with the slab loop software-pipelined across the barrier (SWP)
+            case 9: return launch_dma_cfg<128, 512, 1, 8, 2, 32, 0, true, false, false, true, true>(a, st);        // id 8, same
+            case 14: {                  // DIAGNOSTIC (wrong results): id 11 with per-phase cycle sums written over the output (tools/slab_phases.py)
+                static const bool allow = [] { const char* e = getenv("MNET_ALLOW_DIAGNOSTIC_KERNELS"); return e && atoi(e) != 0; }();
+                if (!allow) return mnet_fail(MNET_E_ARG, "conv: fp16+8 LDS-DMA id 14 is a diagnostic build with wrong results (set MNET_ALLOW_DIAGNOSTIC_KERNELS=1 to use it)");
+                static const bool swp = [] { const char* e = getenv("MNET_DIAG_SWP"); return e && atoi(e) != 0; }();      // the same stamps in the software-pipelined tile (id 15)
+                if (swp) return launch_dma_cfg<256, 256, 2, 4, 2, 32, 6, true, false, false, true, true>(a, st);
+                return launch_dma_cfg<256, 256, 2, 4, 2, 32, 6, true, true, true, true>(a, st);
+            }
             default: return mnet_fail(MNET_E_ARG, "conv: LDS-DMA tile configuration %d has no fp16+8 form", id);
         }
     }
@@ -698,7 +984,9 @@ int conv_dma_pick(const ConvArgs& a) {
     // first group's MFMAs): 472 vs 465 TFLOP/s (+1.5 %); the 128x512 tile does not gain (id 12 stays an A/B knob)
     static const int env_x3_256 = [] { const char* e = getenv("MNET_X3_CFG256"); return e ? atoi(e) : 11; }();
     if (a.split == 2) {
-        static const int env_mx_256 = [] { const char* e = getenv("MNET_MX_CFG256"); return e ? atoi(e) : 11; }();     // A/B knobs (id 11 = id 6 with the LDS reads placed by scheduling hints: 538 vs 530 TFLOP/s)
+        // A/B knobs.  id 15 (round 4) = id 6 with the slab loop software-pipelined across the barrier: +0.5 ... +3.8 % over id 11 (= id 6 with the LDS reads
+        // placed by scheduling hints) on the four shapes that carry the step, +1.2 % end to end, same bytes (profiles/r4g_*)
+        static const int env_mx_256 = [] { const char* e = getenv("MNET_MX_CFG256"); return e ? atoi(e) : 15; }();
         static const int env_mx_128 = [] { const char* e = getenv("MNET_MX_CFG128"); return e ? atoi(e) : 8; }();
         if (a.cout >= 256) return big ? env_mx_256 : (t128 * ((a.cout + 255) / 256) < 200 ? 10 : 1);
         if (a.cout >= 128) return big ? env_mx_128 : (t256 * ((a.cout + 127) / 128) < 200 ? 10 : 2);

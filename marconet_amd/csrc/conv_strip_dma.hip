@@ -381,8 +381,11 @@ int conv_strip_pick(const ConvArgs& a, int dtype, bool explicit_request) {
     // 20 spills) — AUTO keeps the per-tap kernel there unless MNET_STRIP_256=1; the 64x512 tile (8 waves) gains 20 %.
     static const bool auto256 = [] { const char* e = getenv("MNET_STRIP_256"); return e && atoi(e) != 0; }();
     if ((dtype != MNET_F16 && dtype != MNET_F16X2 && dtype != MNET_F16M) || !conv_dma_eligible(a, dtype)) return -1;
-    if (dtype != MNET_F16 && a.cout >= 128) return -1;                   // split-half: the 64x512 tile only (the big tiles take the 8-wave per-tap forms)
-    if (a.cout >= 256 && !explicit_request && !auto256) return -1;
+    // fp16+8, cout >= 256: the 8-wave 256x256 strip tile (round 4) — explicit request or MNET_MX_STRIP256=1 (A/B knob)
+    static const bool mx256 = [] { const char* e = getenv("MNET_MX_STRIP256"); return e && atoi(e) != 0; }();
+    const bool mx_big = dtype == MNET_F16M && a.cout >= 256 && a.cout % 256 == 0 && (explicit_request || mx256);
+    if (dtype != MNET_F16 && a.cout >= 128 && !mx_big) return -1;        // split-half: the 64x512 tile only (the big tiles take the 8-wave per-tap forms)
+    if (a.cout >= 256 && !explicit_request && !auto256 && !mx_big) return -1;
     if (a.kh != 3 || a.kw != 3 || a.sh != 1 || a.sw != 1 || a.ph != 1 || a.pw != 1 || a.c1 != 0 || a.x1) return -1;
     if (a.ho != a.h || a.wo != a.w) return -1;
     int cfg, bp;
@@ -404,6 +407,7 @@ int conv_strip_pick(const ConvArgs& a, int dtype, bool explicit_request) {
 int launch_conv_strip(const ConvArgs& a, hipStream_t st, int cfg) {
     if (a.split == 2) {
         if (cfg == 1) return launch_strip_cfg<64, 512, 1, 8, true, true>(a, st);
+        if (cfg == 0) return launch_strip_cfg<256, 256, 2, 4, true, true>(a, st);      // 8 waves, 128x64 per wave (the per-tap id 6 / 11 tile shape)
         return mnet_fail(MNET_E_ARG, "conv: strip configuration %d has no fp16+8 form", cfg);
     }
     if (a.split) {

@@ -196,7 +196,7 @@ def test_conv_plain(case):
         _check("fp16+8 conv (register-staged) %s" % (case,), got, F.conv2d(x.double(), _wdec(wt).double(), stride=stride, padding=pad), 2e-5)
 
 
-@pytest.mark.parametrize("id_", [0, 1, 2, 3, 4, 5, 6, 7, 8, 10])
+@pytest.mark.parametrize("id_", [0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 15])
 def test_every_lds_dma_tile_configuration(id_):
     """each fp16+8 instantiation of the LDS-DMA kernel, pinned explicitly, with the full epilogue"""
     ops = _ops()
@@ -227,9 +227,74 @@ def test_lds_dma_tiles_agree_bit_for_bit():
     n, h, w, cin, cout = 1, 24, 64, 96, 256
     x = _to_mx(_rnd((n, cin, h, w), 27))
     wp = _pack_w(_rnd((cout, cin, 3, 3), 28, 0.03))
-    outs = [ops.conv2d(x, wp, cout, 3, 3, (1, 1), (1, 1), act=2, algo=16 + i).cpu().view(torch.uint8) for i in (0, 1, 2, 3, 4, 5, 6, 7, 8, 10)]
+    outs = [ops.conv2d(x, wp, cout, 3, 3, (1, 1), (1, 1), act=2, algo=16 + i).cpu().view(torch.uint8) for i in (0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 15)]
     for o in outs[1:]:
         assert torch.equal(outs[0], o)
+
+
+@pytest.mark.parametrize("case", [
+    # cout, cin, k, (n, h, w), software-pipelined id, lock-step id of the same tile
+    (256, 64, 3, (4, 128, 160), 15, 6),       # 320 pixel tiles on <= 256 workgroups: the slab stream crosses tiles, some workgroups run two
+    (256, 32, 1, (4, 128, 160), 15, 6),       # one slab per tile: every iteration closes a tile
+    (128, 64, 3, (2, 128, 320), 9, 8),        # 160 tiles of 128 x 512 (10 DMA pieces per wave per slab)
+    (288, 96, 3, (3, 96, 100), 15, 6),        # cout tail (two channel tiles: the weight scales change per tile), pixel tail, images smaller than a tile row
+    (512, 512, 3, (20, 32, 32), 15, 6),       # 144 slabs per tile, 160 tiles, two channel tiles
+])
+def test_software_pipelined_tiles_equal_the_lock_step_tiles(case):
+    """round 4, ids 15 / 9 (the slab loop pipelined across the barrier: scaled MFMAs of slab s-1 + DMA pieces of slab s+1, then the f16 MFMAs of
+    slab s): same MFMA sequence per output as ids 6 / 8, hence the same bytes — on multi-pass persistent grids, with one slab per tile, with
+    tails, ragged widths, concat-free and the full epilogue (bias, residual, activation)"""
+    ops = _ops()
+    cout, cin, k, (n, h, w), swp, ref = case
+    x = _to_mx(_rnd((n, cin, h, w), 61))
+    wp = _pack_w(_rnd((cout, cin, k, k), 62, 1.0 / math.sqrt(cin * k * k)))
+    bias = _rnd((cout,), 63, 0.3).to(DEV)
+    res = _to_mx(_rnd((n, cout, h, w), 64))
+    vw = torch.tensor([w - 7 * (i % 3) for i in range(n)], dtype=torch.int32, device=DEV)
+    outs = []
+    for i in (ref, swp, swp):
+        y = ops.conv2d(x, wp, cout, k, k, (1, 1), (k // 2, k // 2), bias=bias, residual=res, act=3, valid_w=vw, algo=16 + i)
+        torch.cuda.synchronize()
+        outs.append(y.cpu().view(torch.uint8))
+    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[1], outs[2])
+
+
+def test_software_pipelined_tile_with_concat_sources():
+    """the second concat source (x1) in the pipelined tile: conv_body_32.0's shape class (256 + 64 channels)"""
+    ops = _ops()
+    n, h, w, c0, c1, cout = 40, 32, 64, 64, 32, 256
+    x0, x1 = _to_mx(_rnd((n, c0, h, w), 81)), _to_mx(_rnd((n, c1, h, w), 82))
+    wp = _pack_w(_rnd((cout, c0 + c1, 3, 3), 83, 1.0 / math.sqrt((c0 + c1) * 9)))
+    bias = _rnd((cout,), 84, 0.3).to(DEV)
+    outs = [ops.conv2d(x0, wp, cout, 3, 3, (1, 1), (1, 1), x1=x1, bias=bias, act=2, algo=a_).cpu().view(torch.uint8) for a_ in (16 + 6, 16 + 15)]
+    assert torch.equal(outs[0], outs[1])
+
+
+@pytest.mark.parametrize("case", [
+    # n, h, w, cin, cout
+    (40, 64, 64, 64, 256),        # W < 256: a tile is 4 whole rows; 640 pixel tiles on <= 256 workgroups (multi-pass persistent grid)
+    (2, 64, 1024, 96, 256),       # W >= 256: a tile is 256 pixels of one row; left / right halo from the neighbours
+    (300, 16, 16, 64, 512),       # W = 16 (the smallest strip row), two channel tiles, images smaller than a tile
+    (5, 128, 128, 32, 256),       # one 32-channel slice: 9 slabs per tile, the strip cursor crosses tiles every 3 slabs
+])
+def test_strip_256x256_tile_equals_the_per_tap_tile(case):
+    """round 4: the 8-wave 256x256 strip tile of the fp16+8 mode (one activation strip per filter row instead of one slab per tap:
+    -31 % L2->LDS bytes) runs the MFMA sequence of the per-tap tiles per output -> byte-identical results, with ragged widths, bias,
+    residual and the full epilogue"""
+    ops = _ops()
+    from marconet_amd import _lib
+    n, h, w, cin, cout = case
+    x = _to_mx(_rnd((n, cin, h, w), 71))
+    wp = _pack_w(_rnd((cout, cin, 3, 3), 72, 1.0 / math.sqrt(cin * 9)))
+    bias = _rnd((cout,), 73, 0.3).to(DEV)
+    res = _to_mx(_rnd((n, cout, h, w), 74))
+    vw = torch.tensor([w - 5 * (i % 3) for i in range(n)], dtype=torch.int32, device=DEV)
+    outs = []
+    for algo in (_lib.ALGO_DMA_CFG0 + 6, _lib.ALGO_STRIP_CFG0 + 0, _lib.ALGO_STRIP_CFG0 + 0):
+        y = ops.conv2d(x, wp, cout, 3, 3, (1, 1), (1, 1), bias=bias, residual=res, act=3, valid_w=vw, algo=algo)
+        torch.cuda.synchronize()
+        outs.append(y.cpu().view(torch.uint8))
+    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[1], outs[2])
 
 
 @pytest.mark.parametrize("act", [0, 1, 2, 3, 4, 5, 6])

@@ -18,10 +18,10 @@ def main():
     out = {}
     for b in re.split(r"\n(?=\S)", txt):
         lines = b.strip().split("\n")
-        m = re.match(r"void conv_dma_kernel<(\d+), (\d+), (\d+), (\d+), (\d+), (\d+), 0(?:, (\w+))?(?:, (\w+))?(?:, (\w+))?(?:, (\w+))?>", lines[0])
+        m = re.match(r"void conv_dma_kernel<(\d+), (\d+), (\d+), (\d+), (\d+), (\d+), 0(?:, (\w+))?(?:, (\w+))?(?:, (\w+))?(?:, (\w+))?(?:, (\w+))?>", lines[0])
         if not m:
             continue
-        x3, spread, pipe, mx = (m.group(i) in ("true", "1") for i in (7, 8, 9, 10))
+        x3, spread, pipe, mx, swp = (m.group(i) in ("true", "1") for i in (7, 8, 9, 10, 11))
         c = {}
         for l in lines[1:]:
             q = re.match(r"\s+(\S+)\s+mean/dispatch\s+([\d.]+)\s+dispatches (\d+)", l)
@@ -29,7 +29,7 @@ def main():
                 c[q.group(1)] = (float(q.group(2)), int(q.group(3)))
         f, w = c["FETCH_SIZE"][0], c["WRITE_SIZE"][0]
         gui = c["GRBM_GUI_ACTIVE"][0] / 8.0
-        key = ("conv_dma_kernel<%s,mx%s> f16x2" % (",".join(m.groups()[:6]), ",pipe" if pipe else "") if mx else
+        key = ("conv_dma_kernel<%s,mx%s> f16x2" % (",".join(m.groups()[:6]), ",swp" if swp else (",pipe" if pipe else "")) if mx else
                "conv_dma_kernel<%s%s>%s" % (",".join(m.groups()[:6]), (",spread" if spread else "") + (",pipe" if pipe else ""), " f16x3" if x3 else ""))
         out[key] = {
             "hbm_bytes_per_launch": round((2 * f + w) * 1024),
@@ -47,10 +47,15 @@ def main():
     out["kernel_sources_sha16"] = bench.kernel_sources_sha()
     out["batch"] = int(sys.argv[3]) if len(sys.argv) > 3 else 64
     out["precision"] = sys.argv[4] if len(sys.argv) > 4 else "fp16"
-    try:
-        out["measured_at"] = "commit " + subprocess.check_output(["git", "rev-parse", "--short", "HEAD"], text=True).strip()
-    except Exception:      # noqa: BLE001
-        out["measured_at"] = "?"
+    # the GPU box has no .git: the stamp is the UTC time of the measurement plus the commit handed over in MNET_GIT_COMMIT (or read from git here)
+    import time
+    commit = os.environ.get("MNET_GIT_COMMIT", "")
+    if not commit:
+        try:
+            commit = subprocess.check_output(["git", "rev-parse", "--short", "HEAD"], text=True, stderr=subprocess.DEVNULL).strip()
+        except Exception:      # noqa: BLE001
+            commit = ""
+    out["measured_at"] = time.strftime("%Y-%m-%d %H:%M UTC", time.gmtime()) + (" on commit " + commit if commit else "") + ", kernel sources " + out["kernel_sources_sha16"]
     json.dump(out, open(sys.argv[2], "w"), indent=1)
     print(json.dumps({k: v for k, v in out.items() if k != "_note"}, indent=1))
 

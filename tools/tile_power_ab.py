@@ -19,6 +19,10 @@ sys.path.insert(0, ROOT)
 
 
 def algo_of(i):
+    """LDS-DMA tile id -> algo code; "s<cfg>" = strip configuration <cfg> (MNET_CONV_ALGO_STRIP_CFG0 + cfg)"""
+    if isinstance(i, str) and i.startswith("s"):
+        return 32 + int(i[1:])
+    i = int(i)
     return 16 + i if i < 16 else 64 + i - 16
 
 
@@ -50,6 +54,8 @@ def main():
     ap.add_argument("--only", default="x3:11,x3:20,x2:6,x2:11")
     ap.add_argument("--shape", default="", help="n,h,w,cin,cout of the 3x3 layer (default: --n,64,1024,256,256)")
     ap.add_argument("--ragged", action="store_true", help="valid_w[n] = w - (n % 5) * 3 (glyph windows of different widths)")
+    ap.add_argument("--zeros", action="store_true", help="zero-filled operands: the same instruction stream at a fraction of the switching power "
+                                                         "(what the schedule does when the package power cap does not hold the clock down)")
     a = ap.parse_args()
     from marconet_amd import ops, packing
     dev = "cuda"
@@ -60,6 +66,8 @@ def main():
     vw = torch.tensor([w - (i % 5) * 3 for i in range(n)], dtype=torch.int32, device=dev) if a.ragged else None
     x = torch.randn((n, h, w, cin), device=dev)
     wt = torch.randn((cout, cin, 3, 3), device=dev) * 0.02
+    if a.zeros:
+        x, wt = torch.zeros_like(x), torch.zeros_like(wt)
     bias = torch.zeros(cout, device=dev)
     dts = {"x3": packing.SPLIT_DTYPE, "x2": packing.MX_DTYPE, "f16": torch.float16}
     data = {k: (ops.convert(x, dt), packing.pack_conv_weight(wt, dt), torch.empty((n, h, w, cout), dtype=dt, device=dev)) for k, dt in dts.items()
@@ -69,7 +77,7 @@ def main():
     for arm in a.only.split(","):
         mode, i = arm.split(":")
         xs, ws, out = data[mode]
-        run = lambda: ops.conv2d(xs, ws, cout, 3, 3, (1, 1), (1, 1), bias=bias, act=ops.ACT_LRELU, out=out, valid_w=vw, algo=algo_of(int(i)))
+        run = lambda: ops.conv2d(xs, ws, cout, 3, 3, (1, 1), (1, 1), bias=bias, act=ops.ACT_LRELU, out=out, valid_w=vw, algo=algo_of(i))
         for _ in range(3):
             run()
         torch.cuda.synchronize()
@@ -95,7 +103,7 @@ def main():
         smp.join(timeout=15)
         ms = s.elapsed_time(e) / k
         avg = lambda v: sum(v) / len(v) if v else float("nan")
-        print("%s id %2s: %6.1f TFLOP/s algorithmic (%.3f ms/launch over %d launches) | package %.0f W (max %.0f) | sclk %.0f MHz (%d samples)"
+        print("%s id %3s: %6.1f TFLOP/s algorithmic (%.3f ms/launch over %d launches) | package %.0f W (max %.0f) | sclk %.0f MHz (%d samples)"
               % (mode, i, flops / ms / 1e9, ms, k, avg(smp.w), max(smp.w) if smp.w else float("nan"), avg(smp.clk), len(smp.w)), flush=True)
 
 
