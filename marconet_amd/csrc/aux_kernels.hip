@@ -955,9 +955,21 @@ __global__ void __launch_bounds__(256) torgb_kernel(const T* __restrict__ x, con
     const T* xb = x + (size_t)n * HW * C + (size_t)ch * 8;
     const int h2 = H >> 1, w2_ = W >> 1;
     const float* kb = skip ? skip + (size_t)n * h2 * w2_ * 4 : nullptr;
-    for (int pix = blockIdx.x * ppb + pl; pix < HW; pix += gridDim.x * ppb) {
-        float v[8];
-        ld8<T>(xb + (size_t)pix * C, v);
+    // four pixels per trip: their loads are issued together (one load in flight per lane measured 2.7 TB/s on the 128-px level)
+    constexpr int U = 4;
+    const int step = gridDim.x * ppb;
+    for (int pix0 = blockIdx.x * ppb + pl; pix0 < HW; pix0 += U * step) {
+        float vv[U][8];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int pq = pix0 + u * step;
+            ld8<T>(xb + (size_t)(pq < HW ? pq : pix0) * C, vv[u]);
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+        const int pix = pix0 + u * step;
+        if (pix >= HW) break;                                      // (uniform over the lanes of a pixel: they share pix)
+        const float* v = vv[u];
         float p0 = 0.f, p1 = 0.f, p2 = 0.f;
 #pragma unroll
         for (int j = 0; j < 8; ++j) { const float m = v[j] * s8[j]; p0 = fmaf(m, w0[j], p0); p1 = fmaf(m, w1[j], p1); p2 = fmaf(m, w2[j], p2); }
@@ -977,6 +989,7 @@ __global__ void __launch_bounds__(256) torgb_kernel(const T* __restrict__ x, con
             r0 += up[0]; r1 += up[1]; r2 += up[2];
         }
         *reinterpret_cast<f32x4*>(out + ((size_t)n * HW + pix) * 4) = f32x4{tanhf(r0 - r0 + r0), tanhf(r1 - r1 + r1), tanhf(r2 - r2 + r2), 0.f};
+        }
     }
 }
 
@@ -987,8 +1000,8 @@ extern "C" int mnet_torgb(const void* x, int32_t dtype, int32_t n, int32_t h, in
     MNET_CHECK_ARG(c >= 64 && c <= 512 && (c & (c - 1)) == 0, "torgb: c=%d (supported: 64, 128, 256, 512)", c);
     MNET_CHECK_ARG(!skip || (h % 2 == 0 && w % 2 == 0), "torgb: a skip image needs even h, w");
     MNET_CHECK_ALIGN(aligned16(x) && aligned16(skip) && aligned16(out) && (!is_split4(dtype) || aligned128(x)), "torgb: unaligned pointer");
-    const long long groups = ((long long)h * w + (256 / (c / 8)) - 1) / (256 / (c / 8));
-    const int gx = (int)(groups < 4096 ? groups : 4096);
+    const long long groups = (((long long)h * w + (256 / (c / 8)) - 1) / (256 / (c / 8)) + 3) / 4;      // four pixels per thread and trip
+    const int gx = (int)(groups < 1024 ? groups : 1024);
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     if (dtype == MNET_F16) hipLaunchKernelGGL(torgb_kernel<f16>, dim3(gx, n), dim3(256), 0, st, (const f16*)x, wgt, style, scale_b, bias, skip, out, h, w, c);
     else if (dtype == MNET_F16X2) hipLaunchKernelGGL(torgb_kernel<hs>, dim3(gx, n), dim3(256), 0, st, (const hs*)x, wgt, style, scale_b, bias, skip, out, h, w, c);

@@ -391,7 +391,19 @@ class TSPSRNet(nn.Module, _Precision):
         self.conv_64_fuse = _seq(ResTextBlockV2(2 * D, D))
         self.dim = D
         self.precision = default_precision()
+        # OPT-IN per-layer precision plan (tools/precision_plan.py): "fp16" runs the two conv_*_scale branches (models/networks.py:
+        # 377-381,446) in plain fp16 — the layers whose demotion costs the SR output least on regular strips (+0.9e-4 / +1.1e-4 each at the 64-px
+        # scale, emulated; 3.3e-4 instead of 2.0e-4 on the bench batch, measured).  NOT the default: on the reference's edge-window examples
+        # (glyph windows clipped at the strip border) the same plan measures 1.09e-3 — over the bar.  None: off.
+        self.scale_branch_precision = None
         self._cache = PackCache()
+
+    def _scale_branch_pack(self):
+        """packed weights the conv_*_scale branches run with, or None when they follow the module's precision mode"""
+        want = self.scale_branch_precision
+        if want is None or want == self.precision or self.precision == "fp32":
+            return None
+        return self._cache.get(self, want, self._build), torch_dtype(want)
 
     # ------------------------------------------------------------------ packing (SN fold, K18)
     def _build(self, dtype):
@@ -464,7 +476,11 @@ class TSPSRNet(nn.Module, _Precision):
                                                *pk["conv_%s_fuse.0.norm1" % tag], 1e-6)
         fused = self._res_block(pk, "conv_%s_fuse.0" % tag, cat, valid_w=tab.g_w, norm1_affine=(s1, h1))
         del cat
-        sc = self._two(pk, "conv_%s_scale" % tag, fused, valid_w=tab.g_w)
+        sb = self._scale_branch_pack()
+        if sb is None:
+            sc = self._two(pk, "conv_%s_scale" % tag, fused, valid_w=tab.g_w)
+        else:                                                    # precision plan: this branch in another storage / arithmetic (see __init__)
+            sc = ops.convert(self._two(sb[0], "conv_%s_scale" % tag, ops.convert(fused, sb[1]), valid_w=tab.g_w), fused.dtype)
         sh = self._two(pk, "conv_%s_shift" % tag, fused, valid_w=tab.g_w)
         return ops.glyph_scatter_affine(feat, sc, sh, tab.g_start, tab.g_x1, tab.g_w)        # ori + (f*scale+shift)
 

@@ -382,14 +382,18 @@ def save_packed(path, **roots):
     for rname, root in roots.items():
         for hname, m in _holders(root):
             prec = _holder_precision(m)
-            pk = m._cache.get(m, prec, m._build)
-            key = "%s|%s" % (rname + ("." + hname if hname else ""), prec)
-            flat, tree = {}, {}
-            _flatten(pk, "", flat, tree)
-            trees[key] = tree
-            digests[key] = _weights_digest(m)
-            for p, t in flat.items():
-                tensors[key + "|" + p] = t
+            m._cache.get(m, prec, m._build)
+            # the holder's own precision, plus every other precision it has ALREADY packed for (the batched driver runs the generator's
+            # image-only levels in plain fp16 inside the fp16x2 / fp16x3 modes: that second pack belongs to the blob as well)
+            digest = _weights_digest(m)
+            for pr in [prec] + sorted(k for k in m._cache._store if k != prec):
+                key = "%s|%s" % (rname + ("." + hname if hname else ""), pr)
+                flat, tree = {}, {}
+                _flatten(m._cache._store[pr], "", flat, tree)
+                trees[key] = tree
+                digests[key] = digest
+                for p, t in flat.items():
+                    tensors[key + "|" + p] = t
     if not tensors:
         raise ValueError("save_packed: no packed-weight holders in the given modules")
     save_file(tensors, path, metadata={"format": PACK_FORMAT, "layout": str(PACK_LAYOUT), "abi": str(_abi_version()),
@@ -420,10 +424,11 @@ def load_packed(path, verify=True, **roots):
                 if verify and _weights_digest(m) != digests[key]:
                     raise ValueError("packed blob %s was made from different weights than %s.%s carries" % (path, rname, hname))
                 dev = next(m.parameters()).device
-                pk = _unflatten("", lambda p: f.get_tensor(key + "|" + p).to(dev), trees[key])
                 sig = PackCache.signature(m)
                 if m._cache._sig != sig:
                     m._cache._store, m._cache._sig = {}, sig
-                m._cache._store[prec] = pk
-                attached.append(key)
+                stem = key.rsplit("|", 1)[0] + "|"
+                for k2 in [key] + sorted(k for k in trees if k.startswith(stem) and k != key):     # further precisions of the same holder, if stored
+                    m._cache._store[k2[len(stem):]] = _unflatten("", lambda p, k2=k2: f.get_tensor(k2 + "|" + p).to(dev), trees[k2])
+                    attached.append(k2)
     return attached

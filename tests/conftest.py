@@ -59,6 +59,9 @@ def golden():
 # precisions / call forms of the product against the SAME oracle evaluation.  The oracle is a pure function of its arguments, so
 # its four expensive entry points are memoised for the session: tensors keyed by content, state_dicts by identity (kept alive by
 # the cache, so an id is never reused).  Results are returned as fresh clones.
+_SD_DIGESTS = {}      # id(dict) -> (dict kept alive, cheap signature, content digest)
+
+
 def _memo_key(v, keep):
     import hashlib
     import torch
@@ -66,8 +69,23 @@ def _memo_key(v, keep):
         t = v.detach().cpu().contiguous()
         return ("t", tuple(t.shape), str(t.dtype), hashlib.blake2b(t.reshape(-1).view(torch.uint8).numpy().tobytes(), digest_size=16).hexdigest())
     if isinstance(v, dict):
-        keep.append(v)
-        return ("sd", id(v))
+        # state_dicts are keyed by CONTENT (an id() key returned stale results after an in-place edit).  The digest of ~200
+        # tensors costs ~0.3 s, so it is cached per dict object and recomputed when the cheap signature — keys, tensor versions,
+        # storage addresses — changes
+        sig = tuple((k, getattr(t, "_version", None), t.data_ptr() if isinstance(t, torch.Tensor) else None) for k, t in v.items())
+        ent = _SD_DIGESTS.get(id(v))
+        if ent is None or ent[0] is not v or ent[1] != sig:
+            h = hashlib.blake2b(digest_size=16)
+            for k in sorted(v):
+                h.update(k.encode())
+                t = v[k]
+                if isinstance(t, torch.Tensor):
+                    h.update(t.detach().cpu().contiguous().reshape(-1).view(torch.uint8).numpy().tobytes())
+                else:
+                    h.update(repr(t).encode())
+            ent = (v, sig, h.hexdigest())
+            _SD_DIGESTS[id(v)] = ent
+        return ("sd", ent[2])
     if isinstance(v, (list, tuple)):
         return ("l",) + tuple(_memo_key(e, keep) for e in v)
     if v is None or isinstance(v, (bool, int, float, str)):

@@ -23,9 +23,17 @@ def _free_port():
     return p
 
 
-@pytest.mark.parametrize("total", [5, 2])
-def test_sharded_forward_equals_single_gpu(total, tmp_path):
-    world = 2
+def _worlds():
+    """every rank count this box can run: 2, 4, 8 up to min(device_count, 8) (not a fixed 2).  Collected on a 1-GPU box
+    (or here, without a GPU) the list still holds 2 so that the skip is visible in the report."""
+    n = min(torch.cuda.device_count(), 8) if torch.cuda.is_available() else 0
+    return [w for w in (2, 4, 8) if w <= n] or [2]
+
+
+@pytest.mark.parametrize("world", _worlds())
+@pytest.mark.parametrize("total", [5, 2, 16])
+def test_sharded_forward_equals_single_gpu(total, world, tmp_path):
+    """uneven shards (5 strips), more ranks than strips (2 strips on 4 / 8 ranks: empty shards take part in the collective), even shards (16)"""
     if torch.cuda.device_count() < world:
         pytest.skip("needs %d GPUs, %d visible" % (world, torch.cuda.device_count()))
     port, out = _free_port(), str(tmp_path / "res.json")

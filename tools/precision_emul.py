@@ -102,7 +102,7 @@ def i8_pair_w(w):
 def make_conv(scheme):
     def conv(x, w, bias=None, stride=1, padding=0, dilation=1, groups=1):
         kw = dict(stride=stride, padding=padding, dilation=dilation, groups=groups)
-        if scheme == "f16":
+        if scheme in ("f16", "f16s"):
             y = _conv2d(split(x)[0], split(w)[0], None, **kw)
         elif scheme == "x3":
             xh, xl = split(x)
@@ -135,6 +135,8 @@ def make_conv(scheme):
             raise ValueError(scheme)
         if bias is not None:
             y = y + bias.reshape(1, -1, 1, 1)
+        if scheme == "f16s":            # plain-f16 STORAGE of the layer's output as well (the product's f16 kernels write halves)
+            y = split(y)[0]
         return y
     return conv
 

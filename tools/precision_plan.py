@@ -7,7 +7,8 @@ the product's arithmetic (ResNet: three f16 products; TSPGAN / TSPSRNet: hi.hi +
 builds the largest set that keeps the SR deviation under a budget.
 
     python tools/precision_plan.py sweep  [n_glyphs=16] [seed=1234]      one layer at a time → table
-    python tools/precision_plan.py plan   name1,name2,...  [n] [seed]    a given set → SR max-abs
+    python tools/precision_plan.py plan   name1,name2=f16s,...  [n] [seed]    a given set → SR max-abs (scheme per name: f16 = plain-f16 operands [default],
+                                                                          f16s = plain-f16 operands AND output storage, x3, mx8, fp32)
 Layer names are the reference's module paths (models/networks.py): conv_final.3, conv_64_fuse.0.conv1, TextGenerator.convs.7, ...; a name
 matches every conv whose path STARTS with it."""
 import os
@@ -137,7 +138,7 @@ def main():
     print("strip seed %d, %d glyphs; reference + baseline chain: %.0f s" % (seed, n, time.time() - t), flush=True)
     print("baseline (ResNet x3, TSPGAN / TSPSRNet fp16+8): SR max-abs %.3e" % e0, flush=True)
     if mode == "plan":
-        y = run(sde, sdg, sds, lq, labels, locs, {k: "f16" for k in names}, cache)
+        y = run(sde, sdg, sds, lq, labels, locs, {k.split("=")[0]: (k.split("=")[1] if "=" in k else "f16") for k in names}, cache)
         print("plan f16 on {%s}: SR max-abs %.3e (mean %.3e)" % (", ".join(names), (y - ref).abs().max().item(), (y - ref).abs().mean().item()))
         return
     rows = []
