@@ -145,7 +145,14 @@ enum { MNET_CONV_ALGO_AUTO = 0, MNET_CONV_ALGO_REG_STAGED = 1, MNET_CONV_ALGO_LD
                                        *   id 17: the same form of the 128x512 tile (64x128 per wave)
                                        * same MFMA sequence as ids 0-6: identical bits */,
        MNET_CONV_ALGO_FLAG_ONE_TILE = 256 /* OR-ed in: LDS-DMA kernel launched with one workgroup per tile instead of its
-                                            * persistent grid (A/B measurements only; same results) */ };
+                                            * persistent grid (A/B measurements only; same results) */,
+       MNET_CONV_ALGO_FLAG_X1_CENTER = 512 /* OR-ed in (round 4): the SECOND source x1 contributes through the filter's CENTRE tap only —
+                                             * y = conv_khxkw(x0; W[:, :, :, :c0]) + conv_1x1(x1; W[:, kh/2, kw/2, c0:]) in ONE k-loop: the 1x1
+                                             * skip convolution of ResTextBlockV2 (models/networks.py:504-505,514-515: h + conv_out(x)) folded
+                                             * into its conv2 as extra K instead of a separate launch + a residual read.  wgt is the ordinary
+                                             * [cout][kh][kw][c0+c1] tensor whose x1 part is only read at the centre tap; x1 is NHWC
+                                             * [n,h,w,c1] like x0 (stride 1 launches).  LDS-DMA kernel only (MNET_E_ARG when the launch is
+                                             * not eligible for it); mnet_conv2d_flops still counts x1 at every tap. */ };
 int mnet_conv2d_nhwc_ex(const mnet_conv_desc* d, int32_t algo, void* stream);
 
 /* split-K form of the skinny kernel for a "patchify" conv (filter == stride, no padding; fp32; <= 512 output pixels) — the

@@ -13,6 +13,7 @@ ABI_VERSION = 3               # MNET_ABI_VERSION of include/marconet_hip.h this 
 MNET_F32, MNET_F16, MNET_F16X2, MNET_F16M = 0, 1, 2, 3
 ACT_NONE, ACT_RELU, ACT_LRELU, ACT_LRELU_SQRT2, ACT_TANH, ACT_GELU, ACT_SIGMOID = range(7)
 ALGO_AUTO, ALGO_REG_STAGED, ALGO_LDS_DMA, ALGO_SKINNY, ALGO_DMA_CFG0, ALGO_STRIP_CFG0, ALGO_DMA_CFG16, ALGO_FLAG_ONE_TILE = 0, 1, 2, 3, 16, 32, 64, 256
+ALGO_FLAG_X1_CENTER = 512     # x1 contributes through the filter's centre tap only (a 1x1 skip conv folded into the k-loop)
 
 c_int, c_void_p, c_float, c_double, c_i64 = ctypes.c_int32, ctypes.c_void_p, ctypes.c_float, ctypes.c_double, ctypes.c_int64
 

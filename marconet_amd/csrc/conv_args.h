@@ -16,6 +16,8 @@ struct ConvArgs {
                              // halves then 32 lo halves); cout stays logical; the epilogue multiplies the accumulator by 2^-8 and stores hi/lo
     int mx_fetch_pad;        // fp16+8 launches, A/B knob (env MNET_MX_FETCH_PAD=1): also fetch the padding chunk 7 of every activation block (whole 128-byte lines)
     int one_tile_per_wg;     // A/B knob (MNET_CONV_ALGO_FLAG_ONE_TILE): grid = #tiles instead of a persistent grid
+    int x1_center;           // MNET_CONV_ALGO_FLAG_X1_CENTER: the second source is walked at the centre tap only (LDS-DMA kernels: ktiles = taps * c0 / 64 + c1 / 64,
+    int center_tap, center_tpx;   //   physical channels); its tap index kh/2 * kw + kw/2 and input-pixel offset kh/2 * w + kw/2 relative to tap 0
 };
 
 // conv_igemm_dma.hip

@@ -512,7 +512,8 @@ static int conv_prepare(const mnet_conv_desc* d, int32_t algo, ConvArgs& a) {
     a.one_tile_per_wg = (algo & MNET_CONV_ALGO_FLAG_ONE_TILE) ? 1 : 0;
     static const int env_fetch_pad = [] { const char* e = getenv("MNET_MX_FETCH_PAD"); return e ? atoi(e) : 0; }();   // A/B knob, see ConvArgs
     a.mx_fetch_pad = env_fetch_pad;
-    algo &= ~MNET_CONV_ALGO_FLAG_ONE_TILE;
+    a.x1_center = (algo & MNET_CONV_ALGO_FLAG_X1_CENTER) ? 1 : 0;
+    algo &= ~(MNET_CONV_ALGO_FLAG_ONE_TILE | MNET_CONV_ALGO_FLAG_X1_CENTER);
     MNET_CHECK_ARG((algo >= 0 && algo <= 3) || (algo >= MNET_CONV_ALGO_DMA_CFG0 && algo < MNET_CONV_ALGO_DMA_CFG0 + 16) ||
                    (algo >= MNET_CONV_ALGO_STRIP_CFG0 && algo < MNET_CONV_ALGO_STRIP_CFG0 + 3) ||
                    (algo >= MNET_CONV_ALGO_DMA_CFG16 && algo < MNET_CONV_ALGO_DMA_CFG16 + 16), "conv: bad algo %d", algo);
@@ -557,15 +558,31 @@ static int conv_prepare(const mnet_conv_desc* d, int32_t algo, ConvArgs& a) {
     a.in_swish = d->in_swish; a.act = d->act; a.res_mod = d->res_mod;
     const int bk = d->dtype == MNET_F32 ? 32 : 64;
     a.ktiles = (a.K + bk - 1) / bk; a.tilesC = 0; a.ntiles = 0;
+    a.center_tap = (d->kh / 2) * d->kw + d->kw / 2;
+    a.center_tpx = (d->kh / 2) * d->w + d->kw / 2;
+    if (a.x1_center) {
+        MNET_CHECK_ARG(d->x1 && d->c1 > 0 && (d->kh & 1) && (d->kw & 1) && d->stride_h == 1 && d->stride_w == 1 &&
+                       d->pad_h == d->kh / 2 && d->pad_w == d->kw / 2 && d->dtype != MNET_F32,
+                       "conv: MNET_CONV_ALGO_FLAG_X1_CENTER needs a second source, an odd filter, stride 1, 'same' padding and a half-range dtype");
+        MNET_CHECK_ARG(a.c0 % 64 == 0 && a.c1 % 64 == 0, "conv: MNET_CONV_ALGO_FLAG_X1_CENTER needs c0, c1 in whole k-slabs");
+        a.ktiles = d->kh * d->kw * (a.c0 / 64) + a.c1 / 64;      // (physical channels: 64 halves per slab row)
+    }
     return MNET_OK;
 }
 
 // resolves `algo` to the kernel that runs: MNET_CONV_ALGO_REG_STAGED, MNET_CONV_ALGO_SKINNY, MNET_CONV_ALGO_DMA_CFG0 + id or
 // MNET_CONV_ALGO_STRIP_CFG0 + id (negative: error)
 static int conv_resolve(const mnet_conv_desc* d, int32_t algo, const ConvArgs& a) {
-    algo &= ~MNET_CONV_ALGO_FLAG_ONE_TILE;
+    algo &= ~(MNET_CONV_ALGO_FLAG_ONE_TILE | MNET_CONV_ALGO_FLAG_X1_CENTER);
     static const bool no_strip = [] { const char* e = getenv("MNET_DMA_NO_STRIP"); return e && atoi(e) != 0; }();   // A/B knob
     const bool dma_ok = conv_dma_eligible(a, d->dtype);
+    if (a.x1_center) {          // only the LDS-DMA kernels walk the second source at one tap
+        if (!dma_ok || algo == MNET_CONV_ALGO_REG_STAGED || algo == MNET_CONV_ALGO_SKINNY || (algo >= MNET_CONV_ALGO_STRIP_CFG0 && algo < MNET_CONV_ALGO_DMA_CFG16))
+            return mnet_fail(MNET_E_ARG, "conv: MNET_CONV_ALGO_FLAG_X1_CENTER needs a launch the LDS-DMA kernel takes");
+        if (algo >= MNET_CONV_ALGO_DMA_CFG0) return algo;
+        const int id = conv_dma_pick(a);
+        return id < 16 ? MNET_CONV_ALGO_DMA_CFG0 + id : MNET_CONV_ALGO_DMA_CFG16 + (id - 16);
+    }
     const int strip = conv_strip_pick(a, d->dtype, algo >= MNET_CONV_ALGO_STRIP_CFG0);
     if (algo >= MNET_CONV_ALGO_DMA_CFG16) {
         if (!dma_ok) return mnet_fail(MNET_E_ARG, "conv: this launch is not eligible for the LDS-DMA kernel");

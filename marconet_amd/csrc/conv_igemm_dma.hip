@@ -172,6 +172,18 @@ __global__ void __launch_bounds__(WC * WP * 64, WC * WP / 4) conv_dma_kernel(con
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rW, (lds_void*)(sw_ + (wave + NW * j) * 1024), 16, vo, 0, 0, 0);
         }
     };
+    // k-slab cursor: filter taps inner, 64-channel slices outer; with p.x1_center the slices of the SECOND source have one slab each, at the
+    // centre tap (the 1x1 skip convolution folded into the k-loop, MNET_CONV_ALGO_FLAG_X1_CENTER)
+    auto advance_cursor = [&]() __attribute__((always_inline)) {
+        cur_k += 64;
+        if (p.x1_center && cur_c >= p.c0) { cur_c += 64; return; }
+        ++cur_tap;
+        if (++cur_s == p.kw) { cur_s = 0; cur_tpx += p.w - (p.kw - 1); } else { ++cur_tpx; }
+        if (cur_tap == p.kh * p.kw) {
+            cur_tap = 0; cur_s = 0; cur_tpx = 0; cur_c += 64;
+            if (p.x1_center && cur_c >= p.c0) { cur_tap = p.center_tap; cur_tpx = p.center_tpx; }
+        }
+    };
     auto issue_x = [&](int stage) __attribute__((always_inline)) {
         unsigned char* sx_ = smem + stage * STAGE + BC * 128;
         bool skip = false;
@@ -196,9 +208,7 @@ __global__ void __launch_bounds__(WC * WP * 64, WC * WP / 4) conv_dma_kernel(con
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(rX0, (lds_void*)(sx_ + (wave + NW * j) * 1024), 16, vo, 0, 0, 0);
             }
         }
-        cur_k += 64; ++cur_tap;
-        if (++cur_s == p.kw) { cur_s = 0; cur_tpx += p.w - (p.kw - 1); } else { ++cur_tpx; }
-        if (cur_tap == p.kh * p.kw) { cur_tap = 0; cur_s = 0; cur_tpx = 0; cur_c += 64; }
+        advance_cursor();
     };
     auto issue_slab = [&](int stage) __attribute__((always_inline)) { issue_w(stage); issue_x(stage); };
 
@@ -543,9 +553,7 @@ __global__ void __launch_bounds__(WC * WP * 64, WC * WP / 4) conv_dma_kernel(con
             }
         };
         auto sw_end = [&]() __attribute__((always_inline)) {
-            cur_k += 64; ++cur_tap;
-            if (++cur_s == p.kw) { cur_s = 0; cur_tpx += p.w - (p.kw - 1); } else { ++cur_tpx; }
-            if (cur_tap == p.kh * p.kw) { cur_tap = 0; cur_s = 0; cur_tpx = 0; cur_c += 64; }
+            advance_cursor();
             i_stage ^= 1;
             ++i_kt;
         };

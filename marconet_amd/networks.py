@@ -23,6 +23,7 @@ from .resnet import resnet45stride as resnet45
 from .textvit_arch import TextViT as TextEncoder
 
 _STYLE_NORM = not bool(int(os.environ.get("MNET_NO_STYLE_NORM", "0")))     # A/B knob (tests): style rows normalised by a power of two
+_FOLD_SKIP = not bool(int(os.environ.get("MNET_NO_FOLD_SKIP", "0")))       # A/B knob: ResTextBlockV2's 1x1 skip conv as extra K of its conv2
 RGB_PAD = 8      # 3-channel tensors are carried with 8 channels (one 16-byte fp16 chunk); 32 in the split-half mode (rgb_pad)
 
 
@@ -422,6 +423,19 @@ class TSPSRNet(nn.Module, _Precision):
             pk[name + ".norm2"] = (f(m.norm2.weight), f(m.norm2.bias))
             if hasattr(m, "conv_out"):
                 pk[name + ".conv_out"] = dict(w=pack_conv_weight(m.conv_out.weight.detach(), dtype), b=f(m.conv_out.bias))
+                if dtype != torch.float32 and m.conv_out.weight.is_cuda:
+                    # round 4: h + conv_out(x) (models/networks.py:514-515) folded into conv2's k-loop — one weight tensor [cout][3][3][C + Cin]
+                    # whose second part is the 1x1 skip weight at the centre tap (MNET_CONV_ALGO_FLAG_X1_CENTER), one bias.  Layout plumbing only:
+                    # the spectral-norm fold of conv2 is the library's (fp32 pack), the skip weights are copied into a zero tensor
+                    c2 = m.conv2
+                    w2 = pack_conv_weight(c2.weight_orig.detach(), torch.float32, cin_mult=1, cout_mult=1, sn=(c2.weight_u, c2.weight_v))   # [O][3][3][I], folded
+                    w2 = w2.reshape(c2.out_channels, 3, 3, c2.in_channels).permute(0, 3, 1, 2)
+                    wo = m.conv_out.weight.detach().float()
+                    wz = torch.zeros((wo.shape[0], wo.shape[1], 3, 3), dtype=torch.float32, device=wo.device)
+                    wz[:, :, 1, 1] = wo[:, :, 0, 0]
+                    pk[name + ".conv2+out"] = dict(w=pack_conv_weight(torch.cat([w2, wz], dim=1).contiguous(), dtype),
+                                                   b=pack_vec(c2.bias.detach() + m.conv_out.bias.detach(), pk[name + ".conv2"]["cout"]),
+                                                   cout=pk[name + ".conv2"]["cout"])
 
         for name in ("conv_first_32", "conv_first_16"):
             sn(name + ".0", getattr(self, name)[0])
@@ -462,6 +476,9 @@ class TSPSRNet(nn.Module, _Precision):
         s2, h2 = ops.groupnorm_affine(h, *pk[name + ".norm2"], 1e-6, valid_w)
         ops.affine_act(h, s2, h2, swish=True, out=h)            # in place: h has no other reader
         skip = x
+        if (name + ".conv2+out") in pk and _FOLD_SKIP:
+            L = pk[name + ".conv2+out"]       # the 1x1 skip conv as extra K of conv2: no separate launch, no residual read in the epilogue
+            return ops.conv2d(h, L["w"], L["cout"], 3, 3, (1, 1), (1, 1), x1=x, bias=L["b"], valid_w=valid_w, x1_center=True)
         if (name + ".conv_out") in pk:
             co = pk[name + ".conv_out"]
             skip = ops.conv2d(x, co["w"], co["b"].numel(), bias=co["b"])

@@ -136,9 +136,10 @@ stats = _Stats()
 @_plumbing
 def conv2d(x0, wgt, cout, kh=1, kw=1, stride=(1, 1), pad=(0, 0), x1=None, in_scale=None, in_shift=None,
            in_swish=False, valid_w=None, out_scale=None, bias=None, residual=None, res_mod=0, act=ACT_NONE,
-           post_scale=None, out=None, algo=0, splitk=0):
+           post_scale=None, out=None, algo=0, splitk=0, x1_center=False):
     """mnet_conv2d_nhwc(_ex).  x0 [N,H,W,C0] (+ optional x1 [N,H,W,C1]); wgt packed [cout,kh,kw,C0+C1] same dtype.
-    ``splitk`` > 0: mnet_conv2d_splitk with that many K-slices (fp32 filter == stride convs over <= 512 output pixels)."""
+    ``splitk`` > 0: mnet_conv2d_splitk with that many K-slices (fp32 filter == stride convs over <= 512 output pixels).
+    ``x1_center``: x1 enters through the filter's centre tap only (MNET_CONV_ALGO_FLAG_X1_CENTER: a 1x1 skip conv as extra K)."""
     lib = _lib.load()
     _need_cuda(x0, x1, wgt, in_scale, in_shift, valid_w, out_scale, bias, residual, post_scale, out)
     n, h, w, c0 = x0.shape
@@ -183,6 +184,10 @@ def conv2d(x0, wgt, cout, kh=1, kw=1, stride=(1, 1), pad=(0, 0), x1=None, in_sca
         raise TypeError("conv2d: valid_w must be int32")
     if residual is not None and residual.dtype != x0.dtype:
         raise TypeError("conv2d: residual dtype mismatch")
+    if x1_center:
+        if x1 is None:
+            raise RuntimeError("conv2d: x1_center needs x1")
+        algo |= _lib.ALGO_FLAG_X1_CENTER
     if splitk:
         ws = torch.empty((splitk * n * ho * wo * cout,), dtype=torch.float32, device=x0.device)
         if stats.enabled:
@@ -192,6 +197,8 @@ def conv2d(x0, wgt, cout, kh=1, kw=1, stride=(1, 1), pad=(0, 0), x1=None, in_sca
         return out
     if stats.enabled:
         fl = lib.mnet_conv2d_flops(ctypes.byref(d))
+        if x1_center:                       # the second source is multiplied at one tap, not kh * kw
+            fl -= 2.0 * n * ho * wo * cout * (kh * kw - 1) * c1
         stats.conv_flops += fl
         stats.conv_launches += 1
         if stats.timing:

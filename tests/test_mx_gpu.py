@@ -466,3 +466,56 @@ def test_conv_fuzz_all_paths_agree(case):
     xs[0, :, :, int(vw[0]):] = 0
     ref = F.leaky_relu(F.conv2d(xs.double(), wt.double(), stride=stride, padding=pad) + bias[None, :, None, None].double(), 0.2) * 2 ** 0.5
     _check("fp16+8 conv fuzz %s" % (case,), a[:1].cpu().permute(0, 3, 1, 2), ref, TOL_MX)
+
+
+@pytest.mark.parametrize("storage", ["f16", "x3", "x2"])
+@pytest.mark.parametrize("case", [
+    # n, h, w, c (conv2 input), cx (skip input), cout, pinned LDS-DMA id or None
+    (40, 64, 64, 64, 128, 256, None),      # AUTO at a big launch (x2: the software-pipelined tile; two k regimes: 9 slabs per slice, then 1)
+    (3, 20, 36, 32, 64, 256, None),        # a small launch (the 3-/4-stage tiles), pixel tail
+    (5, 32, 48, 64, 64, 96, 3),            # cout tail on the 64x256 tile
+    (40, 64, 64, 32, 32, 256, 6),          # the lock-step 8-wave tile
+])
+def test_skip_conv_folded_as_extra_k(storage, case):
+    """MNET_CONV_ALGO_FLAG_X1_CENTER (round 4): y = conv3x3(h) + conv1x1(x) + b in ONE k-loop — ResTextBlockV2's h + conv_out(x)
+    (models/networks.py:504-505,514-515) without the separate 1x1 launch and the residual read.  Checked against the fp64 evaluation on the
+    stored operands, with ragged widths (the skip pixel of a column >= valid_w is read as zero, like every other tap)"""
+    ops, P = _ops(), _P()
+    n, h, w, c, cx, cout, pin = case
+    dt = {"f16": torch.float16, "x3": P.SPLIT_DTYPE, "x2": P.MX_DTYPE}[storage]
+    tol = {"f16": 2e-3, "x3": 1e-5, "x2": 8e-5}[storage]
+    if storage == "f16" and (c % 64 or cx % 64):
+        pytest.skip("f16 slabs are 64 channels deep")
+    hq, xq = _rnd((n, c, h, w), 91), _rnd((n, cx, h, w), 92)
+    w2 = _rnd((cout, c, 3, 3), 93, 1.0 / math.sqrt(9 * c))
+    wo = _rnd((cout, cx, 1, 1), 94, 1.0 / math.sqrt(cx))
+    bias = _rnd((cout,), 95, 0.3)
+    wz = torch.zeros((cout, cx, 3, 3))
+    wz[:, :, 1, 1] = wo[:, :, 0, 0]
+    wp = P.pack_conv_weight(torch.cat([w2, wz], 1).to(DEV), dt)
+    hd = ops.convert(hq.permute(0, 2, 3, 1).contiguous().to(DEV), dt)
+    xd = ops.convert(xq.permute(0, 2, 3, 1).contiguous().to(DEV), dt)
+    vw = torch.tensor([w - 3 * (i % 4) for i in range(n)], dtype=torch.int32, device=DEV)
+    y = ops.conv2d(hd, wp, cout, 3, 3, (1, 1), (1, 1), x1=xd, bias=bias.to(DEV), valid_w=vw, x1_center=True, algo=0 if pin is None else 16 + pin)
+    got = ops.convert(y, torch.float32).cpu().permute(0, 3, 1, 2)
+    # reference on the STORED operands (what the kernel multiplies), fp64
+    hs = ops.convert(hd, torch.float32).cpu().permute(0, 3, 1, 2).double()
+    xs = ops.convert(xd, torch.float32).cpu().permute(0, 3, 1, 2).double()
+    for i in range(n):
+        hs[i, :, :, int(vw[i]):] = 0
+        xs[i, :, :, int(vw[i]):] = 0
+    wq = w2.half().double() if storage == "f16" else w2.double()
+    woq = wo.half().double() if storage == "f16" else wo.double()
+    ref = F.conv2d(hs, wq, padding=1) + F.conv2d(xs, woq) + bias.double()[None, :, None, None]
+    scale = float(ref.abs().max())
+    err = float((got.double() - ref).abs().max()) / scale
+    print("folded skip conv %s %s: max rel err %.2e" % (storage, case, err))
+    assert err <= tol
+    # and against the two-launch form it replaces (1x1 conv, then 3x3 with the residual): same up to the storage rounding of the skip tensor
+    wp2, wpo = P.pack_conv_weight(w2.to(DEV), dt), P.pack_conv_weight(wo.to(DEV), dt)
+    skip = ops.conv2d(xd, wpo, cout, bias=bias.to(DEV))
+    y2 = ops.conv2d(hd, wp2, cout, 3, 3, (1, 1), (1, 1), valid_w=vw, residual=skip)
+    got2 = ops.convert(y2, torch.float32).cpu().permute(0, 3, 1, 2)
+    for i in range(n):                    # columns >= valid_w: the two-launch form adds the skip of the UNMASKED x there (never consumed downstream)
+        got2[i, :, :, int(vw[i]):] = got[i, :, :, int(vw[i]):]
+    assert float((got - got2).abs().max()) / scale <= (4e-3 if storage == "f16" else 1e-4)
