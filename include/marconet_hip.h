@@ -127,8 +127,10 @@ int mnet_conv2d_nhwc(const mnet_conv_desc* d, void* stream);
  *      hints; AUTO takes the 8-wave tiles 11 (cout >= 256) / 9 (cout 128) for >= 65536 output pixels
  *   MNET_F16M launches: ids 0-5, 10 = the same tile shapes on v_mfma_f32_32x32x16_f16 + v_mfma_scale_f32_32x32x64_f8f6f4, id 6 = 256x256
  *      8w (128x64 per wave), id 7 / 8 = 128x512 8w (64x128 / 128x64 per wave), ids 11 / 12 / 13 = ids 6 / 8 / 5 with the LDS reads
- *      placed by scheduling hints; AUTO takes 11 (cout >= 256) / 8 (cout 128) / 13 (cout 64) for >= 65536 output pixels; every id
- *      runs the same MFMA sequence per output (same bytes whatever the launch size selects)
+ *      placed by scheduling hints; ids 15 / 9 (round 4) = ids 6 / 8 with the slab loop software-pipelined across the slab barrier (the scaled
+ *      MFMAs of slab s-1 and one DMA piece of slab s+1 behind each, then the f16 MFMAs of slab s); AUTO takes 15 (cout >= 256) / 8 (cout 128) /
+ *      13 (cout 64) for >= 65536 output pixels; every id runs the same MFMA sequence per output (same bytes whatever the launch size selects);
+ *      id 14: DIAGNOSTIC build (per-phase cycle sums written over the output, tools/slab_phases.py), refused unless MNET_ALLOW_DIAGNOSTIC_KERNELS=1
  *   MNET_F16 ids 11-15 ONLY: diagnostic builds used by tools/wg_timeline.py and tools/conv_bench.py; they produce WRONG results and
  *      are refused (MNET_E_ARG) unless the process sets MNET_ALLOW_DIAGNOSTIC_KERNELS=1 */
 enum { MNET_CONV_ALGO_AUTO = 0, MNET_CONV_ALGO_REG_STAGED = 1, MNET_CONV_ALGO_LDS_DMA = 2,
@@ -138,7 +140,8 @@ enum { MNET_CONV_ALGO_AUTO = 0, MNET_CONV_ALGO_REG_STAGED = 1, MNET_CONV_ALGO_LD
        MNET_CONV_ALGO_STRIP_CFG0 = 32 /* + id: the 3x3 "strip" LDS-DMA kernel (one activation strip per filter row shared by its
                                         * three taps; id 0: 256x256 tile, id 1: 64x512 tile).  Eligible: 3x3/stride 1/pad 1, one
                                         * source, cout >= 256 (id 0) or < 128 (id 1), >= 65536 output pixels, whole-row tiles.
-                                        * AUTO uses id 1 when eligible (id 0 measured neutral: explicit request only; MNET_F16X2: id 1 only).  Same k order and MFMA as the LDS-DMA kernel → identical bits. */,
+                                        * AUTO uses id 1 when eligible (id 0 measured neutral: explicit request only; MNET_F16X2: id 1 only; MNET_F16M: id 1, and id 0 as an
+                                        * 8-wave 256x256 tile on explicit request — measured -3 ... -5 %).  Same k order and MFMA as the LDS-DMA kernel → identical bits. */,
        MNET_CONV_ALGO_DMA_CFG16 = 64 /* + (id - 16): LDS-DMA tile configurations 16.. (the ids 0..15 above are full):
                                        *   id 16: 256x256 8w 2st (128x64 per wave) with both half slabs' operand fragments requested up front and the
                                        *          next slab's DMA pieces issued between the halves — AUTO's f16 choice for cout >= 256, >= 65536 pixels
