@@ -512,6 +512,11 @@ __global__ void __launch_bounds__(WC * WP * 64, WC * WP / 4) conv_dma_kernel(con
 
     if constexpr (SWP) {
         constexpr int FA = FC / 2, FB = FP / 2;
+#if defined(MNET_SWP_PRIO) && MNET_SWP_PRIO == 1
+        if (wave >= NW / 2) __builtin_amdgcn_s_setprio(1);              // A/B build: static priority for the later-dispatched wave of every SIMD
+#elif defined(MNET_SWP_PRIO) && MNET_SWP_PRIO == 2
+        if (wave < NW / 2) __builtin_amdgcn_s_setprio(1);               // A/B build: the other way round (control)
+#endif
         const int l32 = lane & 31, h = lane >> 5;
         // slab issue in pieces (the same addresses as issue_w / issue_x): begin → the stream has another slab (crossing into the next tile if needed)
         auto sw_begin = [&]() __attribute__((always_inline)) -> bool {
