@@ -10,7 +10,7 @@ typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef int i32x8 __attribute__((ext_vector_type(8)));
 
-template <int MODE>      // 0: the slab mix (f16 k-step 0, f16 k-step 1, scaled)  1: 24 f16 MFMAs  2: 12 scaled MFMAs  3: 8 scaled only  4: mix with fp4-typed scaled operands
+template <int MODE>      // 0: the slab mix (f16 k-step 0, f16 k-step 1, scaled)  1: 24 f16 MFMAs  2: 12 scaled MFMAs  3: 8 scaled only  4 / 5: mix with fp4- / fp6-typed scaled operands  6: 8 fp6-typed scaled only
 __global__ void __launch_bounds__(512) k(int iters, const float* seed, float* out, unsigned long long* cyc) {
     const int lane = threadIdx.x & 63;
     f32x16 acc[8];
@@ -32,7 +32,7 @@ __global__ void __launch_bounds__(512) k(int iters, const float* seed, float* ou
     __syncthreads();
     const unsigned long long t0 = __builtin_readcyclecounter();
     for (int it = 0; it < iters; ++it) {
-        if (MODE == 0 || MODE == 1 || MODE == 4) {
+        if (MODE == 0 || MODE == 1 || MODE == 4 || MODE == 5) {
 #pragma unroll
             for (int k2 = 0; k2 < 2; ++k2)
 #pragma unroll
@@ -61,6 +61,13 @@ __global__ void __launch_bounds__(512) k(int iters, const float* seed, float* ou
 #pragma unroll
                 for (int fb = 0; fb < 2; ++fb)
                     acc[fa * 2 + fb] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a8[fa + 2], b8[fb], acc[fa * 2 + fb], 0, 0, 0, sa, 0, sb);
+        }
+        if (MODE == 5 || MODE == 6) {
+#pragma unroll
+            for (int fa = 0; fa < 4; ++fa)
+#pragma unroll
+                for (int fb = 0; fb < 2; ++fb)
+                    acc[fa * 2 + fb] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a8[fa], b8[fb], acc[fa * 2 + fb], 2, 2, 0, sa, 0, sb);   // fp6 (e2m3) x fp6
         }
         if (MODE == 4) {
 #pragma unroll
@@ -117,6 +124,8 @@ int main(int argc, char** argv) {
         run<2>("12 x v_mfma_scale_f32_32x32x64_f8f6f4 (fp8)", 12 * 64, waves, ncu, seed, out, dcyc);
         run<0>("slab mix: 16 f16 + 8 scaled fp8", 16 * 32 + 8 * 64, waves, ncu, seed, out, dcyc);
         run<4>("16 f16 + 8 scaled fp4 x fp4", 16 * 32 + 8 * 32, waves, ncu, seed, out, dcyc);
+        run<5>("16 f16 + 8 scaled fp6 x fp6", 16 * 32 + 8 * 32, waves, ncu, seed, out, dcyc);
+        run<6>("8 scaled fp6 x fp6", 8 * 32, waves, ncu, seed, out, dcyc);
     }
     return 0;
 }

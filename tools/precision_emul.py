@@ -60,6 +60,14 @@ def _fp6_e2m3(v):
     return torch.sign(v) * torch.round(a / step) * step
 
 
+def _fp6_e3m2(v):
+    # e3m2: 1 sign, 3 exponent (bias 3), 2 mantissa; max 28, min normal 0.25, subnormal step 0.0625
+    a = v.abs().clamp(max=28.0)
+    e = torch.floor(torch.log2(a.clamp(min=1e-30))).clamp(min=-2, max=4)
+    step = torch.pow(2.0, e - 2)
+    return torch.sign(v) * torch.round(a / step) * step
+
+
 def mx_pair(v, dim, q=_fp8, top=7):
     """(hi8, lo8) of v with one shared exponent per 32-channel block; the lo scale is the hi scale 2^-11."""
     hi, lo = split(v)
@@ -109,8 +117,8 @@ def make_conv(scheme):
             wh, wl = split(w)
             xl, wl = split(xl)[0], split(wl)[0]
             y = _conv2d(xh, wh, None, **kw) + _conv2d(xl, wh, None, **kw) + _conv2d(xh, wl, None, **kw)
-        elif scheme in ("mx8", "mx8x", "mx6"):
-            q, top = (_fp6_e2m3, 2) if scheme == "mx6" else (_fp8, 7)
+        elif scheme in ("mx8", "mx8x", "mx6", "bf6"):
+            q, top = (_fp6_e2m3, 2) if scheme == "mx6" else (_fp6_e3m2, 4) if scheme == "bf6" else (_fp8, 7)
             xh, xh8, xl8 = mx_pair(x, 1, q, top)
             wh, wh8, wl8 = mx_pair(w, 1, q, top)
             y = _conv2d(xh, wh, None, **kw) + _conv2d(xl8, wh8, None, **kw)

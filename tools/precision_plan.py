@@ -25,6 +25,7 @@ sys.path.insert(0, os.path.join(ROOT, "tools"))
 import precision_emul as E  # noqa: E402
 from oracle import marconet_oracle as O  # noqa: E402
 
+DEFAULT_SCHEME = os.environ.get("MNET_EMUL_DEFAULT", "mx8")      # arithmetic of the TSPGAN / TSPSRNet convs that the plan leaves alone
 _CUR = {"name": None, "default": None, "plan": {}, "seen": []}
 _CONVS = {}
 
@@ -107,13 +108,13 @@ def run(sde, sdg, sds, lq, labels, locs, plan, cache):
         _, _, w = cache["enc"]
         gan_touched = any(k.startswith("TextGenerator") for k in plan)
         if gan_touched or "gan" not in cache:
-            with Emulated("mx8", plan):
+            with Emulated(DEFAULT_SCHEME, plan):
                 g = O.tspgan_forward(sdg, w[:1].repeat(n, 1), labels[0])
             if not gan_touched:
                 cache["gan"] = g
         else:
             g = cache["gan"]
-        with Emulated("mx8", plan):
+        with Emulated(DEFAULT_SCHEME, plan):
             return O.tspsr_forward(sds, lq, [g[1]], [g[2]], locs)
 
 
