@@ -175,6 +175,7 @@ def conv_roofline(ops, steps, alg_gf_step, prefer_dtype, batch=None, precision=N
         "GB_per_s": round(tail_bytes / max(tail_ms, 1e-9) / 1e6, 1), "peak_GB_per_s": 8000.0,
         "frac": round(tail_bytes / max(tail_ms, 1e-9) / 1e6 / 8000.0, 4),
         "bytes_note": "algorithmic: every input and output tensor of a launch once, in its storage type (4 bytes per element in the fp16x2 / fp16x3 modes)",
+        "copy_rate_note": "a pure copy with these kernels' access shape measured 5.76-5.79 TB/s on MI355X (profiles/r4n_stream_pattern_microbench.txt)",
         "by_kernel": {k: {"ms_per_step": round(v[0] / max(steps, 1), 3), "GB_per_s": round(v[1] / max(v[0], 1e-9) / 1e6, 1), "launches_per_step": v[2] // max(steps, 1)}
                       for k, v in sorted(tail.items(), key=lambda kv: -kv[1][0])},
     }

@@ -359,6 +359,22 @@ def test_gan_small_ops():
 
 
 @pytest.mark.parametrize("dtype", ALL_DTYPES)
+@pytest.mark.parametrize("hw", [(37, 41), (64, 96)])
+def test_affine_act_on_larger_maps(dtype, hw):
+    """maps of several workgroups per image, ragged (37 x 41: the last workgroup is partly idle) and even (64 x 96)"""
+    ops = _ops()
+    n, c = 2, 64
+    x = _q(_rnd((n, c, hw[0], hw[1]), 150), dtype)
+    sc, sh = _rnd((n, c), 151) + 1.0, _rnd((n, c), 152, 0.3)
+    t = x * sc[:, :, None, None] + sh[:, :, None, None]
+    xd = _nhwc(x, dtype)
+    _check("affine_act swish %s %s" % (dtype, hw), _nchw(ops.affine_act(xd, sc.to(DEV), sh.to(DEV), swish=True)), t * torch.sigmoid(t), dtype)
+    _check("affine_act affine %s %s" % (dtype, hw), _nchw(ops.affine_act(xd, sc.to(DEV), sh.to(DEV))), t, dtype)
+    ops.affine_act(xd, sc.to(DEV), sh.to(DEV), swish=True, out=xd)       # in place
+    _check("affine_act in-place %s %s" % (dtype, hw), _nchw(xd), t * torch.sigmoid(t), dtype)
+
+
+@pytest.mark.parametrize("dtype", ALL_DTYPES)
 def test_post_scale_upsample_scale_affine_act(dtype):
     ops = _ops()
     n, h, w, cin, cout = 3, 6, 10, 32, 64 if dtype in (SPLIT, MX) else 40
