@@ -275,6 +275,11 @@ int mnet_pixelnorm(const float* x, float* y, int32_t N, int32_t D, void* stream)
  * labels int64 [N,nc]; returns MNET_E_ARG-free: out-of-range labels must be rejected by the caller. */
 int mnet_embed_gather(const float* emb, const int64_t* labels, void* out, int32_t dtype, int32_t N,
                       int32_t nc, int32_t C, int32_t num_classes, void* stream);
+/* the same with out[i,y,x,c] multiplied by scale[i,c] (fp32 [N,C], may be NULL) before it is rounded to the storage type: the gathered
+ * constant is read by nothing but the first StyledConv (:289-290), whose input modulation x * s (:284, activation side: SURVEY.md §0.5)
+ * this applies — that conv then needs no modulation prologue */
+int mnet_embed_gather_scaled(const float* emb, const int64_t* labels, const float* scale, void* out, int32_t dtype, int32_t N,
+                             int32_t nc, int32_t C, int32_t num_classes, void* stream);
 /* demod[n,o] = rsqrt( sum_i style[n,i]^2 * wsq_t[i,o] + 1e-8 ),  wsq_t[i,o] = scale^2 * sum_k W[o,i,k]^2
  * (ModulatedConv2d :284-287 rewritten for activation-side modulation) */
 int mnet_demod(const float* style, const float* wsq_t, float* demod, int32_t N, int32_t cin,

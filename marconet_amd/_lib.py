@@ -70,6 +70,7 @@ SYMBOLS = {
     "mnet_attention": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_float, c_void_p]),
     "mnet_pixelnorm": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p]),
     "mnet_embed_gather": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    "mnet_embed_gather_scaled": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "mnet_demod": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
     "mnet_argmax_rows": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p]),
     "mnet_convert": (c_int, [c_void_p, c_int, c_void_p, c_int, c_i64, c_void_p]),

@@ -668,7 +668,8 @@ extern "C" int mnet_glyph_scatter_affine(const void* feat, const void* scale, co
 // ============================================================================ SelectText gather
 template <typename T>
 __global__ void __launch_bounds__(256) embed_gather_kernel(const float* __restrict__ emb, const int64_t* __restrict__ labels,
-                                                           T* __restrict__ out, int nc, int C, long long total_chunks) {
+                                                           const float* __restrict__ scale, T* __restrict__ out, int nc, int C,
+                                                           long long total_chunks) {
     constexpr int N = Vec<T>::N;
     const int cpp = C / N;
     for (long long id = (long long)blockIdx.x * blockDim.x + threadIdx.x; id < total_chunks;
@@ -682,13 +683,19 @@ __global__ void __launch_bounds__(256) embed_gather_kernel(const float* __restri
         float v[N];
 #pragma unroll
         for (int j = 0; j < N; ++j) v[j] = e[j];
+        if (scale) {                              // per-(sample, channel) factor: the first StyledConv's modulation, applied before the storage rounding
+            const float* sp = scale + (size_t)i * C + (size_t)ch * N;
+#pragma unroll
+            for (int j = 0; j < N; ++j) v[j] *= sp[j];
+        }
         straw<T>(out + (size_t)id * N, packr<T>(v));
     }
 }
 
-extern "C" int mnet_embed_gather(const float* emb, const int64_t* labels, void* out, int32_t dtype, int32_t N_,
-                                 int32_t nc, int32_t C, int32_t num_classes, void* stream) {
+extern "C" int mnet_embed_gather_scaled(const float* emb, const int64_t* labels, const float* scale, void* out, int32_t dtype, int32_t N_,
+                                        int32_t nc, int32_t C, int32_t num_classes, void* stream) {
     MNET_CHECK_ARG(emb && labels && out && N_ > 0 && nc > 0 && C > 0 && num_classes > 0, "embed_gather: bad args");
+    MNET_CHECK_ALIGN(aligned16(scale), "embed_gather: unaligned scale");
     MNET_CHECK_ARG(dtype == MNET_F32 || dtype == MNET_F16 || is_split4(dtype), "embed_gather: bad dtype");
     const int N = dtype == MNET_F32 ? 4 : 8;
     MNET_CHECK_ALIGN(C % N == 0 && aligned16(out), "embed_gather: unaligned");
@@ -696,12 +703,17 @@ extern "C" int mnet_embed_gather(const float* emb, const int64_t* labels, void* 
     const long long total = (long long)N_ * 16 * nc * (C / N);
     const int blocks = (int)((total + 255) / 256 < 16384 ? (total + 255) / 256 : 16384);
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-    if (dtype == MNET_F16) hipLaunchKernelGGL(embed_gather_kernel<f16>, dim3(blocks), dim3(256), 0, st, emb, labels, (f16*)out, nc, C, total);
-    else if (dtype == MNET_F16X2) hipLaunchKernelGGL(embed_gather_kernel<hs>, dim3(blocks), dim3(256), 0, st, emb, labels, (hs*)out, nc, C, total);
-    else if (dtype == MNET_F16M) hipLaunchKernelGGL(embed_gather_kernel<hm>, dim3(blocks), dim3(256), 0, st, emb, labels, (hm*)out, nc, C, total);
-    else hipLaunchKernelGGL(embed_gather_kernel<float>, dim3(blocks), dim3(256), 0, st, emb, labels, (float*)out, nc, C, total);
+    if (dtype == MNET_F16) hipLaunchKernelGGL(embed_gather_kernel<f16>, dim3(blocks), dim3(256), 0, st, emb, labels, scale, (f16*)out, nc, C, total);
+    else if (dtype == MNET_F16X2) hipLaunchKernelGGL(embed_gather_kernel<hs>, dim3(blocks), dim3(256), 0, st, emb, labels, scale, (hs*)out, nc, C, total);
+    else if (dtype == MNET_F16M) hipLaunchKernelGGL(embed_gather_kernel<hm>, dim3(blocks), dim3(256), 0, st, emb, labels, scale, (hm*)out, nc, C, total);
+    else hipLaunchKernelGGL(embed_gather_kernel<float>, dim3(blocks), dim3(256), 0, st, emb, labels, scale, (float*)out, nc, C, total);
     MNET_LAUNCH_CHECK("embed_gather");
     return MNET_OK;
+}
+
+extern "C" int mnet_embed_gather(const float* emb, const int64_t* labels, void* out, int32_t dtype, int32_t N_,
+                                 int32_t nc, int32_t C, int32_t num_classes, void* stream) {
+    return mnet_embed_gather_scaled(emb, labels, nullptr, out, dtype, N_, nc, C, num_classes, stream);
 }
 
 // ============================================================================ PixelNorm (one wave per row)

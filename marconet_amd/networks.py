@@ -24,6 +24,7 @@ from .textvit_arch import TextViT as TextEncoder
 
 _STYLE_NORM = not bool(int(os.environ.get("MNET_NO_STYLE_NORM", "0")))     # A/B knob (tests): style rows normalised by a power of two
 _FOLD_SKIP = not bool(int(os.environ.get("MNET_NO_FOLD_SKIP", "0")))       # A/B knob: ResTextBlockV2's 1x1 skip conv as extra K of its conv2
+_FUSE_CONV1_MOD = os.environ.get("MNET_NO_FUSE_CONV1_MOD", "0") != "1"      # conv1's style multiply in the SelectText gather (A/B knob)
 RGB_PAD = 8      # 3-channel tensors are carried with 8 channels (one 16-byte fp16 chunk); 32 in the split-half mode (rgb_pad)
 
 
@@ -264,12 +265,15 @@ class TextGenerator(nn.Module):
         lat = ops.pixelnorm(styles)                                            # :170-171
         for w, b in pk["mlp"]:
             lat = ops.linear(lat, w, self.style_dim, bias=b, act=ops.ACT_LRELU_SQRT2)
-        x = ops.embed_gather(pk["emb"], labels, dtype, self.class_num)         # SelectText (:205-215)
         # every layer's modulation at once: [styles, Σ cin]; _mod() / _style() take per-layer column windows of it, per glyph
         self._S = ops.linear(lat, pk["mod_all_w"], pk["mod_total"], bias=pk["mod_all_b"])
         self._gidx = style_index
         s, d = self._style(pk["conv1"])
-        x = self._styled(pk["conv1"], x, s, d, premodulated=False)
+        # SelectText (:205-215) with conv1's modulation ·s riding in the gather (the gathered constant has no other reader): conv1 then runs
+        # without a modulation prologue, i.e. on the LDS-DMA kernels like every other StyledConv (0.97 -> 0.2 ms per 1024 glyphs, 0.56 -> 0.1 ms
+        # for one strip's 16) — `_FUSE_CONV1_MOD = False` keeps the prologue form
+        x = ops.embed_gather(pk["emb"], labels, dtype, self.class_num, scale=s if _FUSE_CONV1_MOD else None)
+        x = self._styled(pk["conv1"], x, s, d, premodulated=_FUSE_CONV1_MOD)
         skip = self._to_rgb(pk["rgb1"], x, None) if need_image else None
         p64 = p32 = None
         for lvl in range(len(pk["rgbs"])):

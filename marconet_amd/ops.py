@@ -380,14 +380,17 @@ def pixelnorm(x):
 
 
 @_plumbing
-def embed_gather(emb, labels, dtype, num_classes):
+def embed_gather(emb, labels, dtype, num_classes, scale=None):
+    """SelectText gather; ``scale`` (fp32 [N, C], optional): per-(sample, channel) factor applied before the storage rounding"""
     lib = _lib.load()
-    _need_cuda(emb, labels)
+    _need_cuda(emb, labels, scale)
     N, nc = labels.shape
     C = emb.shape[1]
+    if scale is not None and (tuple(scale.shape) != (N, C) or scale.dtype != torch.float32 or not scale.is_contiguous()):
+        raise ValueError("embed_gather: scale must be a contiguous fp32 [N, C] tensor")
     out = new_tensor((N, 4, 4 * nc, C), dtype, emb.device)
-    _lib.check(lib.mnet_embed_gather(_p(emb), _p(labels), _p(out), _dt(out), N, nc, C, num_classes, _stream()),
-               "mnet_embed_gather")
+    _lib.check(lib.mnet_embed_gather_scaled(_p(emb), _p(labels), _p(scale), _p(out), _dt(out), N, nc, C, num_classes, _stream()),
+               "mnet_embed_gather_scaled")
     return out
 
 

@@ -335,6 +335,11 @@ def test_gan_small_ops():
         o = ops.embed_gather(emb.to(DEV), labels.to(DEV), dtype, 100)
         ref = torch.cat([emb[labels[:, j]][:, :, None, None].expand(3, 512, 4, 4) for j in range(2)], dim=3)
         assert torch.equal(_nchw(o), _q(ref, dtype))
+        sc = _rnd((3, 512), 43) + 1.5                                      # per-(sample, channel) factor, applied before the rounding
+        o = ops.embed_gather(emb.to(DEV), labels.to(DEV), dtype, 100, scale=sc.to(DEV))
+        assert torch.equal(_nchw(o), _q(ref * sc[:, :, None, None], dtype))
+    with pytest.raises(ValueError):
+        ops.embed_gather(emb.to(DEV), labels.to(DEV), torch.float32, 100, scale=torch.ones(2, 512, device=DEV))
     s = _rnd((9, 256), 41) + 1
     w = _rnd((128, 256, 3, 3), 42)
     scale = 1 / math.sqrt(256 * 9)

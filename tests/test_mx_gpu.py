@@ -368,6 +368,10 @@ def test_pointwise_kernels_match_torch():
     e1 = ops.convert(ops.embed_gather(emb.to(DEV), lab, P.MX_DTYPE, 50), torch.float32).cpu()      # [3,4,4,64]
     want = emb[[3, 49, 0]].reshape(3, 1, 1, 64).expand(3, 4, 4, 64)
     assert torch.equal(e1, _q(want.permute(0, 3, 1, 2).contiguous()).permute(0, 2, 3, 1))
+    sc = (_rnd((3, 64), 57) + 1.5)
+    e2 = ops.convert(ops.embed_gather(emb.to(DEV), lab, P.MX_DTYPE, 50, scale=sc.to(DEV)), torch.float32).cpu()      # ·scale[i, c] before the rounding
+    want2 = (emb[[3, 49, 0]] * sc).reshape(3, 1, 1, 64).expand(3, 4, 4, 64)
+    assert torch.equal(e2, _q(want2.permute(0, 3, 1, 2).contiguous()).permute(0, 2, 3, 1))
 
 
 @pytest.mark.parametrize("G", [5, 300])

@@ -208,6 +208,10 @@ def test_pointwise_kernels_match_the_fp32_kernels():
     e1 = ops.convert(ops.embed_gather(emb, lab, P.SPLIT_DTYPE, 50), torch.float32)
     e2 = ops.embed_gather(emb, lab, torch.float32, 50)
     assert torch.equal(e1.cpu(), _q(e2.cpu()))
+    sc = (_rnd((3, 64), 57) + 1.5).to(DEV)
+    e3 = ops.convert(ops.embed_gather(emb, lab, P.SPLIT_DTYPE, 50, scale=sc), torch.float32)
+    e4 = ops.embed_gather(emb, lab, torch.float32, 50, scale=sc)
+    assert torch.equal(e4.cpu(), (emb[lab[:, 0]] * sc).cpu().reshape(3, 1, 1, 64).expand(3, 4, 4, 64)) and torch.equal(e3.cpu(), _q(e4.cpu()))
 
 
 @pytest.mark.parametrize("G", [5, 300])
