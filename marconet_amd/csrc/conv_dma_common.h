@@ -56,54 +56,74 @@ __device__ __forceinline__ int dma_weight_channel_mx(int row) {
     return (row & ~63) + (((i >> 2) & 1) << 5) + (f << 4) + ((i >> 3) << 2) + (i & 3);
 }
 
+// fp16+8 tiles: does the LDS (160 KiB) have 4 KiB per wave left behind the stages for the epilogue's store transposition?
+#ifndef MNET_MX_XPOSE
+#define MNET_MX_XPOSE 1           // A/B build knob (0: every lane stores its own blocks)
+#endif
+template <int BC, int BP, int STAGES, int NW, bool MX>
+constexpr bool dma_mx_xpose() { return MNET_MX_XPOSE && MX && STAGES * (BC + BP) * 128 + NW * 4096 <= 160 * 1024; }
+
 // Epilogue of an fp16+8 tile (same passes, same order of operations as dma_epilogue): every lane owns, per pixel, FC/4 whole
 // 32-channel blocks.
+// `xpose` (this wave's 4 KiB of LDS behind the stages, or nullptr): a lane's block is 8 x 16 bytes of ONE 128-byte line, and lane l + 1 holds
+// the next PIXEL — written directly, every store instruction puts 16 bytes into 64 different lines (8 partial writes per line: 16384 write
+// requests per 256x256 tile; measured 32 000 cycles per tile, 13 % of a 72-slab tile's time, tools/slab_phases.py --swp).  Through the LDS the
+// pieces change lanes — lane l gets piece l % 4 of the block of lane l / 4 + 16 k — so that a store instruction writes 16 x 64 contiguous bytes.
+// Same bytes at the same addresses.  The pieces sit at slot 4 L + (c ^ (L / 2 % 4)) of the scratch: conflict-free for the 8-lane groups of
+// ds_write_b128 and the 16-lane groups of ds_read_b128 (MI355X_MICROARCH.md, LDS).  One wave's LDS operations execute in order: no waits.
 template <int BC, int BP, int WC, int WP, int FC, int FP>
-__device__ __forceinline__ void dma_epilogue_mx(const ConvArgs& p, const f32x16 (&acc32)[FC / 2][FP / 2], int co0, int pix0, int wc, int wp, int lane) {
+__device__ __forceinline__ void dma_epilogue_mx(const ConvArgs& p, const f32x16 (&acc32)[FC / 2][FP / 2], int co0, int pix0, int wc, int wp, int lane,
+                                                unsigned char* xpose = nullptr) {
     constexpr int NPX = FP / 2, NB = FC / 4;
     const int h = lane >> 5;
     const int last_pix = p.npix - 1;
 #pragma unroll
     for (int px = 0; px < NPX; ++px) {
-        const int pix = pix0 + wp * (BP / WP) + px * 32 + (lane & 31);
+        const int pixb = pix0 + wp * (BP / WP) + px * 32;                   // first pixel of this wave's 32
+        const int pix = pixb + (lane & 31);
         const int n_img = min(pix, last_pix) / p.howo;
 #pragma unroll
         for (int b = 0; b < NB; ++b) {
-            const int co = co0 + wc * (BC / WC) + b * 64 + h * 32;         // first channel of this lane's block
+            const int cob = co0 + wc * (BC / WC) + b * 64;                  // first channel of lane-half 0's block
+            const int co = cob + h * 32;                                    // first channel of this lane's block
             float v[32];
 #pragma unroll
             for (int q = 0; q < 16; ++q) { v[q] = acc32[2 * b][px][q] * MNET_SPLIT_WSCALE_INV; v[16 + q] = acc32[2 * b + 1][px][q] * MNET_SPLIT_WSCALE_INV; }
-            if (co >= p.cout) continue;
-            if (p.out_scale) {
-                const float* sp = p.out_scale + (size_t)n_img * p.cout + co;
+            if (!xpose && co >= p.cout) continue;
+            // (through the LDS every lane takes part: a lane whose block lies beyond cout works on the last block's parameters instead — loads in
+            //  range, no divergent region around 32 live values — and nobody stores its result)
+            const int co_l = xpose ? min(co, p.cout - 32) : co;
+            {
+                if (p.out_scale) {
+                    const float* sp = p.out_scale + (size_t)n_img * p.cout + co_l;
 #pragma unroll
-                for (int q = 0; q < 32; q += 4) { const f32x4 s4 = *reinterpret_cast<const f32x4*>(sp + q); v[q] *= s4[0]; v[q + 1] *= s4[1]; v[q + 2] *= s4[2]; v[q + 3] *= s4[3]; }
-            }
-            if (p.bias) {
+                    for (int q = 0; q < 32; q += 4) { const f32x4 s4 = *reinterpret_cast<const f32x4*>(sp + q); v[q] *= s4[0]; v[q + 1] *= s4[1]; v[q + 2] *= s4[2]; v[q + 3] *= s4[3]; }
+                }
+                if (p.bias) {
 #pragma unroll
-                for (int q = 0; q < 32; q += 4) { const f32x4 b4 = *reinterpret_cast<const f32x4*>(p.bias + co + q); v[q] += b4[0]; v[q + 1] += b4[1]; v[q + 2] += b4[2]; v[q + 3] += b4[3]; }
-            }
-            if (p.res && pix < p.npix) {
-                const int rpix = p.res_mod > 0 ? pix % p.res_mod : pix;
-                const unsigned char* rb = reinterpret_cast<const unsigned char*>(p.res) + (size_t)rpix * p.cout * 4 + (co >> 5) * 128;
-                const float sl = hm_lo_scale(rb[96]);
+                    for (int q = 0; q < 32; q += 4) { const f32x4 b4 = *reinterpret_cast<const f32x4*>(p.bias + co_l + q); v[q] += b4[0]; v[q + 1] += b4[1]; v[q + 2] += b4[2]; v[q + 3] += b4[3]; }
+                }
+                if (p.res && pix < p.npix) {
+                    const int rpix = p.res_mod > 0 ? pix % p.res_mod : pix;
+                    const unsigned char* rb = reinterpret_cast<const unsigned char*>(p.res) + (size_t)rpix * p.cout * 4 + (co_l >> 5) * 128;
+                    const float sl = hm_lo_scale(rb[96]);
 #pragma unroll
-                for (int c = 0; c < 4; ++c) {
-                    const f16x8 h8 = bitcast<f16x8>(ldg16(rb + c * 16));
-                    float l[8];
-                    hm_decode_lo(*reinterpret_cast<const u32x2*>(rb + 64 + hm_lo_slot(c) * 8), sl, l);
+                    for (int c = 0; c < 4; ++c) {
+                        const f16x8 h8 = bitcast<f16x8>(ldg16(rb + c * 16));
+                        float l[8];
+                        hm_decode_lo(*reinterpret_cast<const u32x2*>(rb + 64 + hm_lo_slot(c) * 8), sl, l);
 #pragma unroll
-                    for (int q = 0; q < 8; ++q) v[c * 8 + q] += (float)h8[q] + l[q];
+                        for (int q = 0; q < 8; ++q) v[c * 8 + q] += (float)h8[q] + l[q];
+                    }
+                }
+                act_apply_vec<32, true>(v, p.act);
+                if (p.post_scale) {
+                    const float* sp = p.post_scale + (size_t)n_img * p.cout + co_l;
+#pragma unroll
+                    for (int q = 0; q < 32; q += 4) { const f32x4 s4 = *reinterpret_cast<const f32x4*>(sp + q); v[q] *= s4[0]; v[q + 1] *= s4[1]; v[q + 2] *= s4[2]; v[q + 3] *= s4[3]; }
                 }
             }
-            act_apply_vec<32, true>(v, p.act);
-            if (p.post_scale) {
-                const float* sp = p.post_scale + (size_t)n_img * p.cout + co;
-#pragma unroll
-                for (int q = 0; q < 32; q += 4) { const f32x4 s4 = *reinterpret_cast<const f32x4*>(sp + q); v[q] *= s4[0]; v[q + 1] *= s4[1]; v[q + 2] *= s4[2]; v[q + 3] *= s4[3]; }
-            }
-            if (pix >= p.npix) continue;
-            unsigned char* yb = reinterpret_cast<unsigned char*>(p.y) + (size_t)pix * p.cout * 4 + (co >> 5) * 128;
+            if (!xpose && pix >= p.npix) continue;
             f16x8 hh[4];
             float m = 0.f;
 #pragma unroll
@@ -112,13 +132,46 @@ __device__ __forceinline__ void dma_epilogue_mx(const ConvArgs& p, const f32x16 
                 for (int q = 0; q < 8; ++q) { hh[c][q] = (f16)v[c * 8 + q]; m = fmaxf(m, fabsf((float)hh[c][q])); }
             const int e8 = hm_e8_of(m);
             u32x2 lo[4];
+            if (!xpose) {
+                unsigned char* yb = reinterpret_cast<unsigned char*>(p.y) + (size_t)pix * p.cout * 4 + (co >> 5) * 128;
 #pragma unroll
-            for (int c = 0; c < 4; ++c) { stg16(yb + c * 16, bitcast<u32x4>(hh[c])); lo[c] = hm_encode_lo(v + c * 8, hh[c], e8); }
-            // lo bytes in the order 0-7,16-23 | 8-15,24-31 (slot of chunk c = hm_lo_slot(c))
-            stg16(yb + 64, u32x4{lo[0][0], lo[0][1], lo[2][0], lo[2][1]});
-            stg16(yb + 80, u32x4{lo[1][0], lo[1][1], lo[3][0], lo[3][1]});
-            stg16(yb + 96, u32x4{(unsigned)e8, 0u, 0u, 0u});
-            stg16(yb + 112, u32x4{0u, 0u, 0u, 0u});
+                for (int c = 0; c < 4; ++c) { stg16(yb + c * 16, bitcast<u32x4>(hh[c])); lo[c] = hm_encode_lo(v + c * 8, hh[c], e8); }
+                // lo bytes in the order 0-7,16-23 | 8-15,24-31 (slot of chunk c = hm_lo_slot(c))
+                stg16(yb + 64, u32x4{lo[0][0], lo[0][1], lo[2][0], lo[2][1]});
+                stg16(yb + 80, u32x4{lo[1][0], lo[1][1], lo[3][0], lo[3][1]});
+                stg16(yb + 96, u32x4{(unsigned)e8, 0u, 0u, 0u});
+                stg16(yb + 112, u32x4{0u, 0u, 0u, 0u});
+                continue;
+            }
+            // ---- through the LDS: two rounds of 4 pieces per lane (the hi halves, then lo bytes | lo bytes | scale | padding)
+            unsigned L = (unsigned)lane;
+            asm volatile("" : "+v"(L));                                     // the scratch addresses are re-derived here: hoisted out of the tile loop they would
+            const unsigned wsw = (L >> 1) & 3u, j = L & 3u;                 // live through the k-loop, which has no register to spare (256 allocated)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) lo[c] = hm_encode_lo(v + c * 8, hh[c], e8);
+#pragma unroll 1
+            for (int half = 0; half < 2; ++half) {
+                u32x4 pc[4];
+                if (half == 0) {
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) pc[c] = bitcast<u32x4>(hh[c]);
+                } else {
+                    pc[0] = u32x4{lo[0][0], lo[0][1], lo[2][0], lo[2][1]};
+                    pc[1] = u32x4{lo[1][0], lo[1][1], lo[3][0], lo[3][1]};
+                    pc[2] = u32x4{(unsigned)e8, 0u, 0u, 0u};
+                    pc[3] = u32x4{0u, 0u, 0u, 0u};
+                }
+#pragma unroll
+                for (int c = 0; c < 4; ++c) *reinterpret_cast<u32x4*>(xpose + ((4u * L + ((unsigned)c ^ wsw)) << 4)) = pc[c];
+#pragma unroll 1
+                for (int k = 0; k < 4; ++k) {                               // (not unrolled: one piece in flight — the epilogue runs with all 128 accumulators live)
+                    const unsigned P = (L >> 2) + 16u * k;                  // the lane whose block this lane helps to write
+                    const u32x4 piece = *reinterpret_cast<const u32x4*>(xpose + ((4u * P + (j ^ ((P >> 1) & 3u))) << 4));
+                    const int ppix = pixb + (int)(P & 31u), pco = cob + (int)(P >> 5) * 32;
+                    if (ppix < p.npix && pco < p.cout)
+                        stg16(reinterpret_cast<unsigned char*>(p.y) + (size_t)ppix * p.cout * 4 + (pco >> 5) * 128 + half * 64 + j * 16, piece);
+                }
+            }
         }
     }
 }

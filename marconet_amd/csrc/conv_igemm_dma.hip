@@ -71,6 +71,9 @@ __global__ void __launch_bounds__(WC * WP * 64, WC * WP / 4) conv_dma_kernel(con
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    // fp16+8 tiles whose stages leave 4 KiB of LDS per wave: the epilogue's stores go through it (dma_epilogue_mx, conv_dma_common.h)
+    constexpr bool XPOSE = dma_mx_xpose<BC, BP, STAGES, NW, MX>();
+    unsigned char* const xpose = XPOSE ? smem + STAGES * STAGE + wave * 4096 : nullptr;
     const int wc = wave / WP, wp = wave % WP;
     const int l16 = lane & 15, g = lane >> 4;
     const int rg = lane >> 3, pc = lane & 7;             // DMA geometry: lane fills LDS row (w + NW j)*8 + rg, 16-byte slot pc
@@ -402,7 +405,7 @@ __global__ void __launch_bounds__(WC * WP * 64, WC * WP / 4) conv_dma_kernel(con
     //   0: LDS reads + the 16 f16 MFMAs   1: issue of the next slab's DMA pieces   2: fp8 conversions + the 8 scaled MFMAs
     //   3: s_waitcnt vmcnt(0)             4: s_barrier
     // (s_memtime needs lgkmcnt(0): each stamp also drains the wave's LDS reads — the stamps sit where the data is needed anyway)
-    unsigned ph_sum[5] = {0u, 0u, 0u, 0u, 0u}, ph_prev = 0u, ph_slabs = 0u;
+    unsigned ph_sum[6] = {0u, 0u, 0u, 0u, 0u, 0u}, ph_prev = 0u, ph_slabs = 0u;      // (software-pipelined form: 0 = the tile-closing epilogue, 5 = the vmcnt(0) right after it)
     auto ph_stamp = [&](int i) __attribute__((always_inline)) {
         if constexpr (DBG == 6) {
             __builtin_amdgcn_sched_barrier(0);
@@ -700,9 +703,11 @@ __global__ void __launch_bounds__(WC * WP * 64, WC * WP / 4) conv_dma_kernel(con
         f16_part(0u);
         c_kt = 1;
         ph_stamp(-1);
+        bool ph_after_epilogue = false;                                  // (DBG == 6 only)
         for (int s = 1; s < total; ++s) {
             VMCNT(0);                                                    // this wave's pieces of slab s (and the previous epilogue's stores) have landed ...
-            ph_stamp(3);                                                 // (DBG == 6 only — phases: 1 front reads + scaled MFMAs + pieces, 2 f16 part, 3 vmcnt(0), 4 barrier)
+            ph_stamp(DBG == 6 && ph_after_epilogue ? 5 : 3);
+            ph_after_epilogue = false;                                                 // (DBG == 6 only — phases: 1 front reads + scaled MFMAs + pieces, 2 f16 part, 3 vmcnt(0), 4 barrier)
             bar();                                                       // ... everyone's; nobody reads the stage of slab s-1 any more
             ph_stamp(4);
             ++ph_slabs;
@@ -718,10 +723,12 @@ __global__ void __launch_bounds__(WC * WP * 64, WC * WP / 4) conv_dma_kernel(con
             if (c_kt == nk) {                                            // slab s-1 closed its tile: epilogue, then the next tile's scales and a clean accumulator
                 int co0, pix0;
                 tile_coords(c_v, co0, pix0);
-                dma_epilogue_mx<BC, BP, WC, WP, FC, FP>(p, acc32, co0, pix0, wc, wp, lane);
+                dma_epilogue_mx<BC, BP, WC, WP, FC, FP>(p, acc32, co0, pix0, wc, wp, lane, xpose);
                 c_kt = 0; c_v += G;
                 if (p.tilesC > 1) load_scales(c_v);                      // (one channel tile: every tile has the same scales)
                 zero_acc();
+                ph_stamp(0);
+                ph_after_epilogue = true;
             }
             __builtin_amdgcn_sched_barrier(0);
             f16_part(so);
@@ -733,7 +740,7 @@ __global__ void __launch_bounds__(WC * WP * 64, WC * WP / 4) conv_dma_kernel(con
         {
             int co0, pix0;
             tile_coords(c_v, co0, pix0);
-            dma_epilogue_mx<BC, BP, WC, WP, FC, FP>(p, acc32, co0, pix0, wc, wp, lane);
+            dma_epilogue_mx<BC, BP, WC, WP, FC, FP>(p, acc32, co0, pix0, wc, wp, lane, xpose);
         }
         if constexpr (DBG == 6) {       // DIAGNOSTIC: phase sums of this wave over the first bytes of the output (32 bytes per wave)
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -741,7 +748,7 @@ __global__ void __launch_bounds__(WC * WP * 64, WC * WP / 4) conv_dma_kernel(con
             if (lane == 0) {
                 unsigned* o = reinterpret_cast<unsigned*>(p.y) + ((size_t)blockIdx.x * NW + wave) * 8;
                 o[0] = 0x5157a3b6u; o[1] = ph_slabs; o[2] = ph_sum[0]; o[3] = ph_sum[1]; o[4] = ph_sum[2]; o[5] = ph_sum[3]; o[6] = ph_sum[4];
-                o[7] = __builtin_amdgcn_s_getreg((31 << 11) | 4);
+                o[7] = ph_sum[5];
             }
         }
         return;
@@ -835,7 +842,7 @@ __global__ void __launch_bounds__(WC * WP * 64, WC * WP / 4) conv_dma_kernel(con
 
         int co0, pix0;
         tile_coords(c_v, co0, pix0);
-        if constexpr (MX) dma_epilogue_mx<BC, BP, WC, WP, FC, FP>(p, acc32, co0, pix0, wc, wp, lane);
+        if constexpr (MX) dma_epilogue_mx<BC, BP, WC, WP, FC, FP>(p, acc32, co0, pix0, wc, wp, lane, xpose);
         else dma_epilogue<BC, BP, WC, WP, MF, DBG, FC, FP, X3>(p, acc, acc32, co0, pix0, wc, wp, lane);
         drain = true;
 
@@ -865,7 +872,7 @@ __global__ void __launch_bounds__(WC * WP * 64, WC * WP / 4) conv_dma_kernel(con
 
 template <int BC, int BP, int WC, int WP, int STAGES, int MF = 16, int DBG = 0, bool X3 = false, bool SPREAD = false, bool PIPE = false, bool MX = false, bool SWP = false>
 static int launch_dma_cfg(const ConvArgs& a, hipStream_t st) {
-    constexpr int LDS = STAGES * (BC + BP) * 128;
+    constexpr int LDS = STAGES * (BC + BP) * 128 + (dma_mx_xpose<BC, BP, STAGES, WC * WP, MX>() ? WC * WP * 4096 : 0);
     auto kern = conv_dma_kernel<BC, BP, WC, WP, STAGES, MF, DBG, X3, SPREAD, PIPE, MX, SWP>;
     static thread_local DeviceOnce attr_once;      // per instantiation, per thread, per device
     if (!attr_once.done()) {

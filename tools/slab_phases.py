@@ -22,7 +22,8 @@ def main():
     a = ap.parse_args()
     if a.swp:
         os.environ["MNET_DIAG_SWP"] = "1"
-        NAMES[:] = ["(unused)", "front LDS reads + 8 scaled MFMAs + 8 DMA pieces", "16 f16 MFMAs + fp8-side reads + cvt", "s_waitcnt vmcnt(0)", "s_barrier"]
+        NAMES[:] = ["tile-closing epilogue (per slab: x slabs per tile = per tile)", "front LDS reads + 8 scaled MFMAs + 8 DMA pieces", "16 f16 MFMAs + fp8-side reads + cvt",
+                    "s_waitcnt vmcnt(0)", "s_barrier", "s_waitcnt vmcnt(0) of the slab after an epilogue (per slab)"]
     from marconet_amd import ops, packing
     n, h, w, cin, cout = (int(v) for v in a.shape.split(","))
     dev = "cuda"
@@ -52,15 +53,20 @@ def main():
     r = raw[ok].double()
     print("%d wave records" % int(ok.sum()))
     slabs = r[:, 1]
-    tot = r[:, 2:7].sum(1) / slabs
+    tot = (r[:, 2:8] if a.swp else r[:, 2:7]).sum(1) / slabs
     hw = raw[ok][:, 7]
     wave_id = torch.arange(raw.shape[0])[ok] % 8
     print("hot slabs per wave %.0f; cycles per hot slab (mean over waves) %.0f  [min %.0f max %.0f]" % (slabs.mean(), tot.mean(), tot.min(), tot.max()))
     for k, nm in enumerate(NAMES):
         v = r[:, 2 + k] / slabs
         print("  %-50s %7.0f cycles (%4.1f %%)   waves 0-3: %6.0f   waves 4-7: %6.0f" % (nm, v.mean(), 100 * v.mean() / tot.mean(), v[wave_id < 4].mean(), v[wave_id >= 4].mean()))
-    simd = (hw >> 4) & 3
-    print("SIMD of waves 0..7 in workgroup 0:", [int(v) for v in simd[:8]])
+    if a.swp:
+        nk = 9 * 2 * cin // 64                     # physical channels: two per logical channel in the blocked storages
+        print("slabs per tile %d: epilogue %.0f cycles per tile, vmcnt(0) after it %.0f cycles per tile, i.e. %.1f slab times per tile"
+              % (nk, (r[:, 2] / slabs).mean() * nk, (r[:, 7] / slabs).mean() * nk, ((r[:, 2] + r[:, 7]) / slabs).mean() * nk / tot.mean()))
+    else:
+        simd = (hw >> 4) & 3
+        print("SIMD of waves 0..7 in workgroup 0:", [int(v) for v in simd[:8]])
 
 
 if __name__ == "__main__":
