@@ -163,13 +163,20 @@ __device__ __forceinline__ void dma_epilogue_mx(const ConvArgs& p, const f32x16 
                 }
 #pragma unroll
                 for (int c = 0; c < 4; ++c) *reinterpret_cast<u32x4*>(xpose + ((4u * L + ((unsigned)c ^ wsw)) << 4)) = pc[c];
-#pragma unroll 1
-                for (int k = 0; k < 4; ++k) {                               // (not unrolled: one piece in flight — the epilogue runs with all 128 accumulators live)
+                u32x4 piece[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
                     const unsigned P = (L >> 2) + 16u * k;                  // the lane whose block this lane helps to write
-                    const u32x4 piece = *reinterpret_cast<const u32x4*>(xpose + ((4u * P + (j ^ ((P >> 1) & 3u))) << 4));
+                    piece[k] = *reinterpret_cast<const u32x4*>(xpose + ((4u * P + (j ^ ((P >> 1) & 3u))) << 4));
+                }
+#pragma unroll
+                for (int k = 0; k < 4; ++k) asm volatile("" : "+v"(piece[k]));   // all four reads in flight (otherwise each is sunk into its store's predicated block: read, wait, store, four times)
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const unsigned P = (L >> 2) + 16u * k;
                     const int ppix = pixb + (int)(P & 31u), pco = cob + (int)(P >> 5) * 32;
                     if (ppix < p.npix && pco < p.cout)
-                        stg16(reinterpret_cast<unsigned char*>(p.y) + (size_t)ppix * p.cout * 4 + (pco >> 5) * 128 + half * 64 + j * 16, piece);
+                        stg16(reinterpret_cast<unsigned char*>(p.y) + (size_t)ppix * p.cout * 4 + (pco >> 5) * 128 + half * 64 + j * 16, piece[k]);
                 }
             }
         }
