@@ -56,12 +56,13 @@ __device__ __forceinline__ int dma_weight_channel_mx(int row) {
     return (row & ~63) + (((i >> 2) & 1) << 5) + (f << 4) + ((i >> 3) << 2) + (i & 3);
 }
 
-// fp16+8 tiles: does the LDS (160 KiB) have 4 KiB per wave left behind the stages for the epilogue's store transposition?
+// fp16+8 tiles: what the LDS (160 KiB) has left per wave behind the stages for the epilogue's store transposition
 #ifndef MNET_MX_XPOSE
 #define MNET_MX_XPOSE 1           // A/B build knob (0: every lane stores its own blocks)
 #endif
-template <int BC, int BP, int STAGES, int NW, bool MX>
-constexpr bool dma_mx_xpose() { return MNET_MX_XPOSE && MX && STAGES * (BC + BP) * 128 + NW * 4096 <= 160 * 1024; }
+// `lds`: the kernel's own bytes → scratch bytes per wave (4096, 1024 or 0)
+template <int NW, bool MX>
+constexpr int dma_mx_xpose_bytes(int lds) { return !(MNET_MX_XPOSE && MX) ? 0 : (lds + NW * 4096 <= 160 * 1024 ? 4096 : (lds + NW * 1024 <= 160 * 1024 ? 1024 : 0)); }
 
 // Epilogue of an fp16+8 tile (same passes, same order of operations as dma_epilogue): every lane owns, per pixel, FC/4 whole
 // 32-channel blocks.
@@ -71,9 +72,12 @@ constexpr bool dma_mx_xpose() { return MNET_MX_XPOSE && MX && STAGES * (BC + BP)
 // pieces change lanes — lane l gets piece l % 4 of the block of lane l / 4 + 16 k — so that a store instruction writes 16 x 64 contiguous bytes.
 // Same bytes at the same addresses.  The pieces sit at slot 4 L + (c ^ (L / 2 % 4)) of the scratch: conflict-free for the 8-lane groups of
 // ds_write_b128 and the 16-lane groups of ds_read_b128 (MI355X_MICROARCH.md, LDS).  One wave's LDS operations execute in order: no waits.
-template <int BC, int BP, int WC, int WP, int FC, int FP>
+// XL: lanes whose blocks fit the scratch at once — 64 (4 KiB per wave) or 16 (1 KiB per wave: the 64-lane round becomes four 16-lane rounds, one
+// read and one store per lane each).
+template <int BC, int BP, int WC, int WP, int FC, int FP, int XL = 64>
 __device__ __forceinline__ void dma_epilogue_mx(const ConvArgs& p, const f32x16 (&acc32)[FC / 2][FP / 2], int co0, int pix0, int wc, int wp, int lane,
                                                 unsigned char* xpose = nullptr) {
+    static_assert(XL == 64 || XL == 16, "scratch of 4 KiB or 1 KiB per wave");
     constexpr int NPX = FP / 2, NB = FC / 4;
     const int h = lane >> 5;
     const int last_pix = p.npix - 1;
@@ -171,22 +175,38 @@ __device__ __forceinline__ void dma_epilogue_mx(const ConvArgs& p, const f32x16 
                     pc[2] = u32x4{(unsigned)e8, 0u, 0u, 0u};
                     pc[3] = u32x4{0u, 0u, 0u, 0u};
                 }
+                if constexpr (XL == 64) {
 #pragma unroll
-                for (int c = 0; c < 4; ++c) *reinterpret_cast<u32x4*>(xpose + ((4u * L + ((unsigned)c ^ wsw)) << 4)) = pc[c];
-                u32x4 piece[4];
+                    for (int c = 0; c < 4; ++c) *reinterpret_cast<u32x4*>(xpose + ((4u * L + ((unsigned)c ^ wsw)) << 4)) = pc[c];
+                    u32x4 piece[4];
 #pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    const unsigned P = (L >> 2) + 16u * k;                  // the lane whose block this lane helps to write
-                    piece[k] = *reinterpret_cast<const u32x4*>(xpose + ((4u * P + (j ^ ((P >> 1) & 3u))) << 4));
-                }
+                    for (int k = 0; k < 4; ++k) {
+                        const unsigned P = (L >> 2) + 16u * k;              // the lane whose block this lane helps to write
+                        piece[k] = *reinterpret_cast<const u32x4*>(xpose + ((4u * P + (j ^ ((P >> 1) & 3u))) << 4));
+                    }
 #pragma unroll
-                for (int k = 0; k < 4; ++k) asm volatile("" : "+v"(piece[k]));   // all four reads in flight (otherwise each is sunk into its store's predicated block: read, wait, store, four times)
+                    for (int k = 0; k < 4; ++k) asm volatile("" : "+v"(piece[k]));   // all four reads in flight (otherwise each is sunk into its store's predicated block: read, wait, store, four times)
 #pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    const unsigned P = (L >> 2) + 16u * k;
-                    const int ppix = pixb + (int)(P & 31u), pco = cob + (int)(P >> 5) * 32;
-                    if (ppix < p.npix && pco < p.cout)
-                        stg16(reinterpret_cast<unsigned char*>(p.y) + (size_t)ppix * p.cout * 4 + (pco >> 5) * 128 + half * 64 + j * 16, piece[k]);
+                    for (int k = 0; k < 4; ++k) {
+                        const unsigned P = (L >> 2) + 16u * k;
+                        const int ppix = pixb + (int)(P & 31u), pco = cob + (int)(P >> 5) * 32;
+                        if (ppix < p.npix && pco < p.cout)
+                            stg16(reinterpret_cast<unsigned char*>(p.y) + (size_t)ppix * p.cout * 4 + (pco >> 5) * 128 + half * 64 + j * 16, piece[k]);
+                    }
+                } else {
+                    const unsigned Lq = L & 15u;
+#pragma unroll 1
+                    for (unsigned r = 0; r < 4; ++r) {                       // the blocks of lanes 16 r .. 16 r + 15
+                        if ((L >> 4) == r) {
+#pragma unroll
+                            for (int c = 0; c < 4; ++c) *reinterpret_cast<u32x4*>(xpose + ((4u * Lq + ((unsigned)c ^ wsw)) << 4)) = pc[c];
+                        }
+                        const unsigned Pq = L >> 2, P = 16u * r + Pq;
+                        const u32x4 piece = *reinterpret_cast<const u32x4*>(xpose + ((4u * Pq + (j ^ ((Pq >> 1) & 3u))) << 4));
+                        const int ppix = pixb + (int)(P & 31u), pco = cob + (int)(P >> 5) * 32;
+                        if (ppix < p.npix && pco < p.cout)
+                            stg16(reinterpret_cast<unsigned char*>(p.y) + (size_t)ppix * p.cout * 4 + (pco >> 5) * 128 + half * 64 + j * 16, piece);
+                    }
                 }
             }
         }

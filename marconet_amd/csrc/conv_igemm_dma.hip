@@ -72,8 +72,8 @@ __global__ void __launch_bounds__(WC * WP * 64, WC * WP / 4) conv_dma_kernel(con
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     // fp16+8 tiles whose stages leave 4 KiB of LDS per wave: the epilogue's stores go through it (dma_epilogue_mx, conv_dma_common.h)
-    constexpr bool XPOSE = dma_mx_xpose<BC, BP, STAGES, NW, MX>();
-    unsigned char* const xpose = XPOSE ? smem + STAGES * STAGE + wave * 4096 : nullptr;
+    constexpr int XB = dma_mx_xpose_bytes<NW, MX>(STAGES * STAGE);     // 4096, 1024 or 0 bytes per wave
+    unsigned char* const xpose = XB ? smem + STAGES * STAGE + wave * XB : nullptr;
     const int wc = wave / WP, wp = wave % WP;
     const int l16 = lane & 15, g = lane >> 4;
     const int rg = lane >> 3, pc = lane & 7;             // DMA geometry: lane fills LDS row (w + NW j)*8 + rg, 16-byte slot pc
@@ -723,7 +723,7 @@ __global__ void __launch_bounds__(WC * WP * 64, WC * WP / 4) conv_dma_kernel(con
             if (c_kt == nk) {                                            // slab s-1 closed its tile: epilogue, then the next tile's scales and a clean accumulator
                 int co0, pix0;
                 tile_coords(c_v, co0, pix0);
-                dma_epilogue_mx<BC, BP, WC, WP, FC, FP>(p, acc32, co0, pix0, wc, wp, lane, xpose);
+                dma_epilogue_mx<BC, BP, WC, WP, FC, FP, (XB == 1024 ? 16 : 64)>(p, acc32, co0, pix0, wc, wp, lane, xpose);
                 c_kt = 0; c_v += G;
                 if (p.tilesC > 1) load_scales(c_v);                      // (one channel tile: every tile has the same scales)
                 zero_acc();
@@ -740,7 +740,7 @@ __global__ void __launch_bounds__(WC * WP * 64, WC * WP / 4) conv_dma_kernel(con
         {
             int co0, pix0;
             tile_coords(c_v, co0, pix0);
-            dma_epilogue_mx<BC, BP, WC, WP, FC, FP>(p, acc32, co0, pix0, wc, wp, lane, xpose);
+            dma_epilogue_mx<BC, BP, WC, WP, FC, FP, (XB == 1024 ? 16 : 64)>(p, acc32, co0, pix0, wc, wp, lane, xpose);
         }
         if constexpr (DBG == 6) {       // DIAGNOSTIC: phase sums of this wave over the first bytes of the output (32 bytes per wave)
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -842,7 +842,7 @@ __global__ void __launch_bounds__(WC * WP * 64, WC * WP / 4) conv_dma_kernel(con
 
         int co0, pix0;
         tile_coords(c_v, co0, pix0);
-        if constexpr (MX) dma_epilogue_mx<BC, BP, WC, WP, FC, FP>(p, acc32, co0, pix0, wc, wp, lane, xpose);
+        if constexpr (MX) dma_epilogue_mx<BC, BP, WC, WP, FC, FP, (XB == 1024 ? 16 : 64)>(p, acc32, co0, pix0, wc, wp, lane, xpose);
         else dma_epilogue<BC, BP, WC, WP, MF, DBG, FC, FP, X3>(p, acc, acc32, co0, pix0, wc, wp, lane);
         drain = true;
 
@@ -872,7 +872,7 @@ __global__ void __launch_bounds__(WC * WP * 64, WC * WP / 4) conv_dma_kernel(con
 
 template <int BC, int BP, int WC, int WP, int STAGES, int MF = 16, int DBG = 0, bool X3 = false, bool SPREAD = false, bool PIPE = false, bool MX = false, bool SWP = false>
 static int launch_dma_cfg(const ConvArgs& a, hipStream_t st) {
-    constexpr int LDS = STAGES * (BC + BP) * 128 + (dma_mx_xpose<BC, BP, STAGES, WC * WP, MX>() ? WC * WP * 4096 : 0);
+    constexpr int LDS = STAGES * (BC + BP) * 128 + WC * WP * dma_mx_xpose_bytes<WC * WP, MX>(STAGES * (BC + BP) * 128);
     auto kern = conv_dma_kernel<BC, BP, WC, WP, STAGES, MF, DBG, X3, SPREAD, PIPE, MX, SWP>;
     static thread_local DeviceOnce attr_once;      // per instantiation, per thread, per device
     if (!attr_once.done()) {

@@ -41,7 +41,8 @@ __global__ void __launch_bounds__(WC * WP * 64, WC * WP / 4) conv_strip_kernel(c
     static_assert(WJ >= 1 && WJ * 8 * NW == BC, "tile / wave-count mismatch");
     static_assert((BC / WC) % 64 == 0 && (BP / WP) % 32 == 0 && SCAP % 8 == 0, "wave tile shape");
     static_assert(!MX || X3, "MX is a 4-byte storage mode");
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];   // [W0][W1][S0][S1]
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];   // [W0][W1][S0][S1][epilogue scratch of the fp16+8 tiles]
+    constexpr int XB = dma_mx_xpose_bytes<NW, MX>(2 * WBYTES + 2 * SBYTES);   // per wave: the epilogue's stores go through it (dma_epilogue_mx)
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -346,14 +347,15 @@ __global__ void __launch_bounds__(WC * WP * 64, WC * WP / 4) conv_strip_kernel(c
         c_sst ^= 1;
         int co0, pix0;
         tile_coords(c_v, co0, pix0);
-        if constexpr (MX) dma_epilogue_mx<BC, BP, WC, WP, FC, FP>(p, acc32, co0, pix0, wc, wp, lane);
+        if constexpr (MX) dma_epilogue_mx<BC, BP, WC, WP, FC, FP, (XB == 1024 ? 16 : 64)>(p, acc32, co0, pix0, wc, wp, lane, XB ? smem + 2 * WBYTES + 2 * SBYTES + wave * XB : nullptr);
         else dma_epilogue<BC, BP, WC, WP, 16, 0, FC, FP, X3>(p, acc, acc32_unused, co0, pix0, wc, wp, lane);
     }
 }
 
 template <int BC, int BP, int WC, int WP, bool X3 = false, bool MX = false>
 static int launch_strip_cfg(const ConvArgs& a, hipStream_t st) {
-    constexpr int LDS = 2 * BC * 128 + 2 * StripCap<BP>::ROWS * 128;
+    constexpr int LDS0 = 2 * BC * 128 + 2 * StripCap<BP>::ROWS * 128;
+    constexpr int LDS = LDS0 + WC * WP * dma_mx_xpose_bytes<WC * WP, MX>(LDS0);
     static_assert(LDS <= 160 * 1024, "LDS budget");
     auto kern = conv_strip_kernel<BC, BP, WC, WP, X3, MX>;
     static thread_local DeviceOnce attr_once;      // per instantiation, per thread, per device
