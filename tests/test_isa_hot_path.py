@@ -1,0 +1,27 @@
+"""CPU: the dominant kernel's k-loop must not touch scratch memory.
+
+hipcc allocates the 256-VGPR LDS-DMA tiles globally: an innocent change in the epilogue or the per-tile set-up can make it spill values of the slab
+loop, and every reload there waits (vmcnt(0)) for the slab's LDS-DMA pieces too — the tile still passes every numerical test and runs 15 % slower
+(DESIGN.md §3.1e).  This cross-compiles the kernel file to gfx950 assembly (≈1 minute, no GPU needed) and lets tools/isa_hot_scratch.py walk the
+software-pipelined fp16+8 256x256 tile's slab loop."""
+import os
+import shutil
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+
+
+@pytest.mark.skipif(not (os.path.exists(HIPCC) or shutil.which("hipcc")), reason="needs hipcc")
+def test_dominant_tile_has_no_scratch_access_in_its_slab_loop(tmp_path):
+    asm = str(tmp_path / "conv_igemm_dma.s")
+    cc = HIPCC if os.path.exists(HIPCC) else shutil.which("hipcc")
+    r = subprocess.run([cc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-S", "--cuda-device-only",
+                        os.path.join(ROOT, "marconet_amd", "csrc", "conv_igemm_dma.hip"), "-o", asm], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "isa_hot_scratch.py"), asm], capture_output=True, text=True, timeout=120)
+    print(r.stdout)
+    assert "scratch accesses on the hot path: 0" in r.stdout and r.returncode == 0, r.stdout + r.stderr
