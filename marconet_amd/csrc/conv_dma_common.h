@@ -139,11 +139,14 @@ __device__ __forceinline__ void dma_epilogue_mx(const ConvArgs& p, const f32x16 
             }
             if (!xpose && pix >= p.npix) continue;
             f16x8 hh[4];
-            float m = 0.f;
+            float m32 = 0.f;
 #pragma unroll
             for (int c = 0; c < 4; ++c)
 #pragma unroll
-                for (int q = 0; q < 8; ++q) { hh[c][q] = (f16)v[c * 8 + q]; m = fmaxf(m, fabsf((float)hh[c][q])); }
+                for (int q = 0; q < 8; ++q) { hh[c][q] = (f16)v[c * 8 + q]; m32 = fmaxf(m32, fabsf(v[c * 8 + q])); }
+            // max |f16(v)| = f16(max |v|) (round-to-nearest is monotonic): one conversion of the maximum instead of 32 of the halves — hipcc folds the
+            // abs of the other form into a second v_cvt_f32_f16 per value, beside the one the lo residual needs
+            const float m = (float)(f16)m32;
             const int e8 = hm_e8_of(m);
             u32x2 lo[4];
             if (!xpose) {
