@@ -18,6 +18,7 @@ struct ConvArgs {
     int one_tile_per_wg;     // A/B knob (MNET_CONV_ALGO_FLAG_ONE_TILE): grid = #tiles instead of a persistent grid
     int x1_center;           // MNET_CONV_ALGO_FLAG_X1_CENTER: the second source is walked at the centre tap only (LDS-DMA kernels: ktiles = taps * c0 / 64 + c1 / 64,
     int center_tap, center_tpx;   //   physical channels); its tap index kh/2 * kw + kw/2 and input-pixel offset kh/2 * w + kw/2 relative to tap 0
+    int howo_shift, wo_shift;     // log2 of ho * wo / of wo when they are powers of two, else -1 (LDS-DMA kernels: the per-tile set-up divides by them, set by the launcher)
 };
 
 // conv_igemm_dma.hip

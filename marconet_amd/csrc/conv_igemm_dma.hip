@@ -99,6 +99,7 @@ __global__ void __launch_bounds__(WC * WP * 64, WC * WP / 4) conv_dma_kernel(con
         return ((unsigned long long)hi << 32) | lo;
     };
     unsigned woff[WJ];                                   // byte offset of this lane's weight chunk at k-slab 0
+    int woff_co0 = -1;                                   // the channel tile woff[] was computed for
     unsigned xpx[XJ], xmask[XJ];                         // activation rows: input pixel of tap 0 (relative to the tile's first image); valid-tap bits
     // 16-byte slot inside the 128-byte slab row, XOR-swizzled on the source side.  Row (wave + NW j)*8 + rg → (row >> 1) & 7 =
     // 4*(wave & 1) + (rg >> 1) for every j (NW is even): ONE value per lane, not one per piece
@@ -119,20 +120,24 @@ __global__ void __launch_bounds__(WC * WP * 64, WC * WP / 4) conv_dma_kernel(con
         bW = (unsigned long long)(reinterpret_cast<const f16*>(p.wgt) + (size_t)co0 * p.K);
         nW = (int)(wbytes < 0x7fffffffLL ? wbytes : 0x7fffffffLL);
         // Activations: base = first image touched by this pixel tile; bound = the images the tile can touch.
-        const int n_first = pix0 / p.howo;
-        const int n_last = (min(pix0 + BP, p.npix) - 1) / p.howo;
+        const bool p2 = p.howo_shift >= 0 && p.wo_shift >= 0;          // (wave-uniform) every map of this network: shifts instead of divisions
+        const int n_first = p2 ? pix0 >> p.howo_shift : pix0 / p.howo;
+        const int n_last = p2 ? (min(pix0 + BP, p.npix) - 1) >> p.howo_shift : (min(pix0 + BP, p.npix) - 1) / p.howo;
         const int nimg = n_last - n_first + 1;
         bX0 = (unsigned long long)(reinterpret_cast<const char*>(p.x0) + (size_t)n_first * img0);
         nX0 = (int)(img0 * nimg);
         bX1 = (unsigned long long)(p.x1 ? reinterpret_cast<const char*>(p.x1) + (size_t)n_first * img1 : reinterpret_cast<const char*>(p.x0));
         nX1 = (int)(p.x1 ? img1 * nimg : 0);
         // Weight rows are permuted on their way into LDS (free: the DMA source address is per lane), see dma_weight_channel
+        if (co0 != woff_co0) {                                          // (wave-uniform; one channel tile: computed once per launch)
+            woff_co0 = co0;
 #pragma unroll
-        for (int j = 0; j < WJ; ++j) {
-            const int row = (wave + NWI * j) * 8 + rg;
-            const int ch = MX ? dma_weight_channel_mx(row) : dma_weight_channel<MF>(row);
-            const int lc = pc ^ ((row >> 1) & 7);
-            woff[j] = (co0 + ch < p.cout) ? (unsigned)(ch * p.K * 2 + lc * 16) : OOB;
+            for (int j = 0; j < WJ; ++j) {
+                const int row = (wave + NWI * j) * 8 + rg;
+                const int ch = MX ? dma_weight_channel_mx(row) : dma_weight_channel<MF>(row);
+                const int lc = pc ^ ((row >> 1) & 7);
+                woff[j] = (co0 + ch < p.cout) ? (unsigned)(ch * p.K * 2 + lc * 16) : OOB;
+            }
         }
         // activation rows: a bit mask of the filter taps whose input pixel exists (inside the image and left of valid_w); kh*kw <= 32 on this path.
         // This runs once per tile between a slab barrier and the slab's MFMAs, on both waves of every SIMD at once (measured: 12 900 cycles per
@@ -143,9 +148,10 @@ __global__ void __launch_bounds__(WC * WP * 64, WC * WP / 4) conv_dma_kernel(con
             const int row = (wave + NWI * j) * 8 + rg;
             const int pix = pix0 + row;
             const int pixc = min(pix, p.npix - 1);                               // (clamped: rows beyond the tensor get an empty mask below)
-            const int n = pixc / p.howo, rem = pixc - n * p.howo;
+            int n, rem, oh, ow;
+            if (p2) { n = pixc >> p.howo_shift; rem = pixc & (p.howo - 1); oh = rem >> p.wo_shift; ow = rem & (p.wo - 1); }
+            else { n = pixc / p.howo; rem = pixc - n * p.howo; oh = rem / p.wo; ow = rem - oh * p.wo; }
             const int xvwj = p.valid_w ? p.valid_w[n] : p.w;
-            const int oh = rem / p.wo, ow = rem - oh * p.wo;
             const int ih0 = oh * p.sh - p.ph, iw0 = ow * p.sw - p.pw;
             const int px = ((n - n_first) * p.h + ih0) * p.w + iw0;
             const int vw = min(xvwj, p.w);
@@ -883,6 +889,8 @@ static int launch_dma_cfg(const ConvArgs& a, hipStream_t st) {
         attr_once.mark();
     }
     ConvArgs b = a;
+    auto log2_or_minus1 = [](int v) { return v > 0 && (v & (v - 1)) == 0 ? __builtin_ctz((unsigned)v) : -1; };
+    b.howo_shift = log2_or_minus1(a.howo); b.wo_shift = log2_or_minus1(a.wo);
     b.tilesC = (a.cout + BC - 1) / BC;
     const int tilesP = (a.npix + BP - 1) / BP;
     b.ntiles = b.tilesC * tilesP;
