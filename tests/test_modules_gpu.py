@@ -556,6 +556,37 @@ def test_generator_chunks_are_bit_exact_and_meet_the_bar(nets, ckpts, precision)
         pipe.set_precision("fp32")
 
 
+@pytest.mark.parametrize("precision", ["fp32", "fp16x2", "fp16x3", "fp16"])
+def test_conv1_modulation_in_the_gather_equals_the_prologue_form(nets, ckpts, precision):
+    """round 4: the first StyledConv's style multiply rides in the SelectText gather (mnet_embed_gather_scaled) instead of the conv prologue.
+    fp32: the same fp32 product feeds the same MFMA sequence — priors bit-identical; the half-range modes round x*s to their storage once in
+    either form but conv1 then runs on a different kernel (LDS-DMA instead of register-staged: other summation order): both forms within the
+    mode's bar of the oracle, and of each other"""
+    from marconet_amd import networks
+    gan = nets[1]
+    n = 6
+    styles = torch.randn(n, 512, generator=torch.Generator().manual_seed(201)).to(DEV)
+    labels = synth.make_labels(202, n).reshape(n, 1).to(DEV)
+    gan.set_precision(precision)
+    old = networks._FUSE_CONV1_MOD
+    try:
+        networks._FUSE_CONV1_MOD = True
+        a = [t.float().cpu() for t in gan(styles, labels, None)]
+        networks._FUSE_CONV1_MOD = False
+        b = [t.float().cpu() for t in gan(styles, labels, None)]
+    finally:
+        networks._FUSE_CONV1_MOD = old
+        gan.set_precision("fp32")
+    with torch.no_grad():
+        ref = O.tspgan_forward(ckpts[1], styles.cpu(), labels.cpu())
+    tol = {"fp32": 1e-4, "fp16": 5e-2}.get(precision, TOL)
+    for name, x, y, r in zip(("image", "prior64", "prior32"), a, b, ref):
+        if precision == "fp32":
+            assert torch.equal(x, y), name
+        assert _err(x, r) <= tol and _err(y, r) <= tol, (name, _err(x, r), _err(y, r))
+        _note("gan.%s.%s.conv1_modulation_gather_vs_prologue.maxabs" % (precision, name), _err(x, y))
+
+
 @pytest.mark.parametrize("precision", ["fp16x2", "fp16x3"])
 def test_prior_image_precision_leaves_sr_bits_unchanged(nets, ckpts, precision):
     """the batched driver runs the generator levels behind the two prior levels (they feed only the structure image it never returns,
