@@ -18,7 +18,12 @@ accuracy), the plain fp16 storage mode (2x faster, ~1e-2 deviation) and the exac
 own batch and the post-processed SR outputs (uint8 BGR, test_sr.py:198-200) are all-gathered over RCCL — the one collective
 of the path.  Rank 0 prints ONE JSON line.
 
-Other BASELINE configs, each with its own roofline of its dominant kernel:
+The default run (N = 1) also carries, under "secondary.configs", a short driver-timed measurement of BASELINE configs[1] (batch 64),
+configs[3] (TSPGAN alone) and configs[4] (mixed widths), each with the roofline fraction of its dominant kernel and a parity sample; under
+"parity" the oracle comparison on TWO weight regimes (marconet_amd/synthetic.py: "tame" and "trained"-like) and — when MARCONET_CKPT_DIR
+holds the reference's real checkpoints (marconet_amd/checkpoints.py) — on those instead of the synthetic ones.
+
+Other BASELINE configs as stand-alone lines, each with its own roofline of its dominant kernel:
     --config gan     configs[3]: the test_w.py StyleGAN-prior path alone — 256 x 16 = 4096 glyphs of 128x128 through TSPGAN
     --config mixed   configs[4]: strips of content width 128..512 bucketed by padded width (MarconetPipeline.forward_mixed_widths),
                      work-balanced over the ranks for N>1
@@ -43,6 +48,7 @@ GF_RESNET, GF_VIT, GF_SR_TRUNK = 108.01, 3.69, 484.12     # GFLOP / image (SURVE
 GF_GAN, GF_SR_PRIOR = 41.78, 47.25                         # GFLOP / glyph
 GF_F16_FIXED = GF_RESNET + GF_SR_TRUNK
 GF_F16_PER_GLYPH = GF_GAN + GF_SR_PRIOR
+GF_GAN_IMAGE_LEVEL = 232.0 / 16.0                          # GFLOP / glyph of TSPGAN's 128-px level (232 of 668 GF per 16 glyphs): feeds only the structure image
 
 # kernel id (mnet_conv2d_plan) → name as it appears in rocprofv3's kernel trace
 KNAME = {1: "conv_igemm_kernel (register-staged)", 3: "conv_skinny_f32_kernel", 16: "conv_dma_kernel<256,256,4,4,2,16>", 17: "conv_dma_kernel<256,128,4,2,3,16>",
@@ -98,6 +104,8 @@ def parse():
                                                                  "all-gather inside the timed region anyway (its cost is reported)")
     ap.add_argument("--cpu-images", type=int, default=4, help="images timed on the host CPU oracle (0 = skip); ~3.5 s each on 32 threads")
     ap.add_argument("--no-secondary", action="store_true", help="skip the secondary throughput measurements")
+    ap.add_argument("--secondary-steps", type=int, default=3, help="timed steps of every secondary measurement (the headline uses --steps)")
+    ap.add_argument("--no-regimes", action="store_true", help="skip the parity sample on the trained-like weight regime")
     ap.add_argument("--cpu-threads", type=int, default=32, help="cap on host threads for the CPU baseline")
     ap.add_argument("--no-gather", action="store_true")
     ap.add_argument("--gather-format", default="u8", choices=["u8", "f32"], help="N>1: what is all-gathered — the post-processed uint8 BGR image (0.75 MiB/img) or the fp32 NCHW tensor (3 MiB/img)")
@@ -204,6 +212,30 @@ def conv_roofline(ops, steps, alg_gf_step, prefer_dtype, batch=None, precision=N
     }, ns_peak
 
 
+def cpu_info():
+    """(model string, logical cores of the host, cores this process may run on)"""
+    model = "?"
+    try:
+        with open("/proc/cpuinfo") as fh:
+            for line in fh:
+                if line.lower().startswith("model name"):
+                    model = line.split(":", 1)[1].strip()
+                    break
+    except OSError:
+        pass
+    try:
+        avail = len(os.sched_getaffinity(0))
+    except AttributeError:
+        avail = os.cpu_count() or 1
+    return model, os.cpu_count() or 1, avail
+
+
+def flat_roofline(r):
+    """the scalars of a roofline dict a reader needs first, without nesting (the driver's parsed record keeps only one level)"""
+    return {"kernel": r["kernel"], "achieved_TFLOPs": r["achieved"], "frac_of_2500": r["frac"], "frac_of_mode_peak": r["frac_of_mode_peak"],
+            "all_conv_TFLOPs": r["all_conv_kernels"]["achieved"], "hbm_tail_ms": r["hbm_tail"]["ms_per_step"], "hbm_tail_GB_per_s": r["hbm_tail"]["GB_per_s"]}
+
+
 def main():
     a = parse()
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -226,21 +258,20 @@ def main():
         # N ranks build the same seeded checkpoints on the host at the same time: do not oversubscribe its cores
         torch.set_num_threads(max(1, min(32, host_threads(1 << 30) // world)))
 
-    from marconet_amd import networks, ops, synthetic
+    from marconet_amd import checkpoints, ops, synthetic
     from marconet_amd.pipeline import MarconetPipeline, OverlappedGather, balance_shards
 
-    sde, sdg, sds = synthetic.make_encoder_state_dict(), synthetic.make_gan_state_dict(), synthetic.make_sr_state_dict()
-    enc, gan, sr = networks.TextContextEncoderV2(), networks.TSPGAN(), networks.TSPSRNet()
-    enc.load_state_dict(sde, strict=True)
-    gan.load_state_dict(sdg, strict=True)
-    sr.load_state_dict(sds, strict=True)
+    # weights: the reference's real checkpoints when MARCONET_CKPT_DIR holds them (marconet_amd/checkpoints.py), else seeded synthetic ones
+    sde, sdg, sds, weights_source = checkpoints.load_state_dicts()
+    enc, gan, sr = checkpoints.build_networks(sde, sdg, sds, dev)
     # the product's defaults (check_finite included: on for the half-range modes, one flag read back per batch)
-    pipe = MarconetPipeline(enc.eval().to(dev), gan.eval().to(dev), sr.eval().to(dev), precision=a.precision)
+    pipe = MarconetPipeline(enc, gan, sr, precision=a.precision)
     pdt = PDT[a.precision]
 
     B, n = a.batch, a.glyphs
     gather = OverlappedGather() if (world > 1 or a.force_gather) and not a.no_gather and a.config != "gan" else None
     u8 = gather is not None and a.gather_format == "u8"
+    sec_steps = max(1, min(a.steps, a.secondary_steps))
 
     def fence():
         if gather is not None:
@@ -250,20 +281,67 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    secondary = None
-    # ------------------------------------------------------------------ workload
-    if a.config == "sr":
-        widths = [512] * B
-        lq = synthetic.make_lq(1234 + rank, B, widths).to(dev)
+    def rate(step_fn, steps, images):
+        """warm-up + ``steps`` timed steps of a secondary measurement → (images/s over all ranks, ms per step)"""
+        step_fn()
+        dts, _, _ = timed(step_fn, fence, steps, world, dev)
+        return round(images * steps / dts, 3), round(dts / steps * 1e3, 3)
+
+    def instrumented(step_fn, steps, alg_gf, batch, precision):
+        """a separate pass with HIP events around every conv launch and every streaming kernel → roofline dict"""
+        ops.stats.reset()
+        ops.stats.enabled = ops.stats.timing = True
+        timed(step_fn, fence, steps, world, dev)
+        ops.stats.enabled = ops.stats.timing = False
+        r, pk = conv_roofline(ops, steps, alg_gf, PDT[precision], batch, precision)
+        ops.stats.reset()
+        return r, pk
+
+    # ------------------------------------------------------------------ workloads (each: step(), images per step, algorithmic GFLOP per step)
+    def sr_workload(Bq):
+        widths = [512] * Bq
+        lq_ = synthetic.make_lq(1234 + rank, Bq, widths).to(dev)
         # labels and glyph locations stay on the HOST, where the OCR / detector front-end leaves them (test_sr.py:121-149):
         # the forward then needs no device→host synchronisation at all
-        labels = [synthetic.make_labels(1234 + 1000 * rank + b, n) for b in range(B)]
-        locs = synthetic.make_locs([n] * B, widths)
+        labels_ = [synthetic.make_labels(1234 + 1000 * rank + b, n) for b in range(Bq)]
+        locs_ = synthetic.make_locs([n] * Bq, widths)
+        return lq_, labels_, locs_
+
+    def gan_workload(N):
+        styles_ = synthetic.make_styles(77 + rank, N).to(dev)
+        glabels_ = synthetic.make_labels(78 + rank, N).to(dev)
+
+        def step_():
+            y_ = None
+            for s_ in range(0, N, pipe.glyph_chunk):                  # bounded working set (8.6 GB of 128-px maps per 1024 glyphs)
+                y_ = gan(styles=styles_[s_:s_ + pipe.glyph_chunk], labels=glabels_[s_:s_ + pipe.glyph_chunk], noise=None)[0]
+            return y_
+        return styles_, glabels_, step_
+
+    def mixed_workload(Bq):
+        # configs[4]: content widths uniform in {128,192,...,512}; n_b = w_b / 32 glyphs; the GLOBAL batch (Bq x world strips,
+        # same on every rank) is split by algorithmic work (pipeline.balance_shards), each rank runs its strips bucketed by width
+        G = Bq * world
+        wsel = synthetic.integers(4321, "mixed.w", (G,), 0, 7).tolist()
+        widths_all = [128 + 64 * int(v) for v in wsel]
+        counts_all = [w_ // 32 for w_ in widths_all]
+        mine = balance_shards(widths_all, counts_all, world)[rank]
+        widths_ = [widths_all[i] for i in mine]
+        counts_ = [counts_all[i] for i in mine]
+        lq_ = synthetic.make_lq(4000 + rank, len(mine), widths_).to(dev)
+        labels_ = [synthetic.make_labels(4100 + i, c) for i, c in zip(mine, counts_)]
+        locs_ = synthetic.make_locs(counts_, widths_, max_glyphs=16)
+        gf = sum(GF_RESNET + GF_SR_TRUNK * w_ / 512.0 + GF_F16_PER_GLYPH * c for w_, c in zip(widths_, counts_))
+        return lq_, widths_, counts_, labels_, locs_, gf
+
+    secondary = None
+    lq = labels = locs = styles = glabels = None
+    if a.config == "sr":
+        lq, labels, locs = sr_workload(B)
         images_per_step = B
         alg_gf_step = B * (GF_F16_FIXED + GF_F16_PER_GLYPH * n)       # algorithmic GFLOP of the non-ViT convs per step
         gf_image = GF_F16_FIXED + GF_F16_PER_GLYPH * n + GF_VIT
-        workload = ("BASELINE.json metric configuration: batch %d synthetic 32x512 LR strips per GPU, %d glyphs/image, %s, "
-                    "encoder+TSPGAN+TSPSRNet, seeded random-init checkpoints" % (B, n, a.precision))
+        workload = "metric config: batch %d x 32x512 LR, %d glyphs/img, enc+TSPGAN+TSPSRNet, %s" % (B, n, a.precision)
 
         def step():
             # N > 1: the all-gather of this step's outputs (the one collective of the path) is enqueued asynchronously and
@@ -274,38 +352,17 @@ def main():
             return y
     elif a.config == "gan":
         N = B * n                                                     # configs[3]: 256 x 16 = 4096 glyph images per step
-        styles = synthetic.make_styles(77 + rank, N).to(dev)
-        glabels = synthetic.make_labels(78 + rank, N).to(dev)
         gan.set_precision(a.precision)
+        styles, glabels, step = gan_workload(N)
         images_per_step = N
         alg_gf_step = N * GF_GAN
         gf_image = GF_GAN
-        workload = ("BASELINE.json configs[3]: test_w.py StyleGAN-prior path alone, %d x %d = %d glyph images (128x128) per GPU per "
-                    "step through TSPGAN in chunks of %d, random styles, %s" % (B, n, N, pipe.glyph_chunk, a.precision))
-
-        def step():
-            y = None
-            for s in range(0, N, pipe.glyph_chunk):                   # bounded working set (8.6 GB of 128-px maps per 1024 glyphs)
-                y = gan(styles=styles[s:s + pipe.glyph_chunk], labels=glabels[s:s + pipe.glyph_chunk], noise=None)[0]
-            return y
+        workload = "configs[3]: TSPGAN alone, %d x %d = %d glyphs of 128x128 per GPU, chunks of %d, %s" % (B, n, N, pipe.glyph_chunk, a.precision)
     else:
-        # configs[4]: content widths uniform in {128,192,...,512}; n_b = w_b / 32 glyphs; the GLOBAL batch (B x world strips,
-        # same on every rank) is split by algorithmic work (pipeline.balance_shards), each rank runs its strips bucketed by width
-        G = B * world
-        wsel = synthetic.integers(4321, "mixed.w", (G,), 0, 7).tolist()
-        widths_all = [128 + 64 * int(v) for v in wsel]
-        counts_all = [w_ // 32 for w_ in widths_all]
-        mine = balance_shards(widths_all, counts_all, world)[rank]
-        widths = [widths_all[i] for i in mine]
-        counts = [counts_all[i] for i in mine]
-        lq = synthetic.make_lq(4000 + rank, len(mine), widths).to(dev)
-        labels = [synthetic.make_labels(4100 + i, c) for i, c in zip(mine, counts)]
-        locs = synthetic.make_locs(counts, widths, max_glyphs=16)
-        images_per_step = len(mine)
-        alg_gf_step = sum(GF_RESNET + GF_SR_TRUNK * w_ / 512.0 + GF_F16_PER_GLYPH * c for w_, c in zip(widths, counts))
-        gf_image = (alg_gf_step + GF_VIT * len(mine)) / max(len(mine), 1)
-        workload = ("BASELINE.json configs[4]: %d strips per GPU of content width uniform in {128..512 step 64}, w/32 glyphs each, "
-                    "bucketed by padded width (64-px buckets), work-balanced shards, %s" % (B, a.precision))
+        lq, widths, counts, labels, locs, alg_gf_step = mixed_workload(B)
+        images_per_step = len(widths)
+        gf_image = (alg_gf_step + GF_VIT * len(widths)) / max(len(widths), 1)
+        workload = "configs[4]: %d strips/GPU, widths {128..512 step 64}, w/32 glyphs, 64-px buckets, %s" % (B, a.precision)
 
         def step():
             outs = pipe.forward_mixed_widths(lq, widths, labels, locs)
@@ -317,10 +374,8 @@ def main():
     dt, per_rank_dt, y = timed(step, fence, a.steps, world, dev)
     # roofline of the dominant kernel: a SEPARATE pass with HIP events around every conv launch (same stream)
     prof_steps = min(a.steps, 2)
-    ops.stats.reset()
-    ops.stats.enabled = ops.stats.timing = True
-    timed(step, fence, prof_steps, world, dev)
-    ops.stats.enabled = ops.stats.timing = False
+    roofline, peak = instrumented(step, prof_steps, alg_gf_step, B if a.config == "sr" else None, a.precision)
+    roofline["measured_in"] = "a separate instrumented pass of %d step(s) after the timed region (HIP events around every conv launch)" % prof_steps
     if y.dtype.is_floating_point:
         assert torch.isfinite(y).all()
     # the timed batch's OWN output, sampled: one strip per generator chunk (4096 glyphs / glyph_chunk 1024 = 4 chunks at the default
@@ -329,6 +384,7 @@ def main():
     samp_idx = sorted(set([0, B // 3, (2 * B) // 3, B - 1])) if a.config == "sr" else []
     y_timed = y[samp_idx].float().cpu() if (a.config == "sr" and y.dtype.is_floating_point and y.dim() == 4 and y.shape[1] == 3) else None
     y_timed_noimg = None
+    del y
     total_images, per_rank_images = images_per_step, [images_per_step]
     if world > 1:
         t = torch.tensor([images_per_step], device=dev, dtype=torch.float64)
@@ -336,29 +392,33 @@ def main():
         dist.all_gather(allc, t)
         per_rank_images = [int(v.item()) for v in allc]
         total_images = sum(per_rank_images)
-    roofline, peak = conv_roofline(ops, prof_steps, alg_gf_step, pdt, B if a.config == "sr" else None, a.precision)
-    roofline["measured_in"] = "a separate instrumented pass of %d step(s) after the timed region (HIP events around every conv launch)" % prof_steps
 
     # ---- secondary figures (reported separately, never the headline)
     if a.config == "sr" and not a.no_secondary:
+        secondary = {"steps_each": sec_steps}
         # the same step without the generator's 128-px structure image, which only feeds test_sr.py's saved visualisation
         pipe.need_prior_image = False
         step()
-        dt2, _, y2 = timed(step, fence, a.steps, world, dev)
+        dt2, _, y2 = timed(step, fence, sec_steps, world, dev)
         pipe.need_prior_image = True
         if y_timed is not None:
             y_timed_noimg = y2[samp_idx].float().cpu()
         del y2
-        secondary = {"images_per_s_without_prior_image": round(total_images * a.steps / dt2, 3), "ms_per_step": round(dt2 / a.steps * 1e3, 3),
-                     "note": "opt-in MarconetPipeline(need_prior_image=False): TSPGAN stops at the 64-px level; SR output identical"}
+        secondary["images_per_s_without_prior_image"] = round(total_images * sec_steps / dt2, 3)
+        secondary["note_without_prior_image"] = "opt-in MarconetPipeline(need_prior_image=False): TSPGAN stops at the 64-px level; SR output identical"
+        if pipe._image_precision() not in (None, a.precision):
+            # the default runs TSPGAN's image-only 128-px level (11.5 % of the algorithmic FLOPs; forward_batch never returns that image) in plain
+            # fp16: here the same step with EVERY level in the mode's own arithmetic (prior_image_precision=None)
+            saved = pipe.prior_image_precision
+            pipe.prior_image_precision = None
+            secondary["images_per_s_all_levels_in_mode_precision"], _ = rate(step, sec_steps, total_images)
+            pipe.prior_image_precision = saved
         if a.precision == "fp16x2":
             # opt-in per-layer precision plan (TSPSRNet.scale_branch_precision = "fp16": the conv_*_scale branches in plain fp16) —
             # not the default (over the bar on edge-clipped glyph windows), timed here with its deviation under parity
             pipe.sr.scale_branch_precision = "fp16"
-            step()
-            dt3, _, _ = timed(step, fence, a.steps, world, dev)
+            secondary["images_per_s_scale_branches_fp16"], _ = rate(step, sec_steps, total_images)
             pipe.sr.scale_branch_precision = None
-            secondary["images_per_s_scale_branches_fp16"] = round(total_images * a.steps / dt3, 3)
         # the other precision modes on the same batch (fp32: a 16-image slice — 54 images/s): the mode that meets the parity bar
         # (fp16x3, or fp32) is always reported next to the fp16 storage mode, with its measured deviation under "parity" below
         for prec in ("fp16x2", "fp16x3", "fp16", "fp32"):
@@ -367,12 +427,9 @@ def main():
             pipe.set_precision(prec)
             kk = min(B, 16) if prec == "fp32" else B
             step_k = (lambda: pipe.forward_batch(lq[:kk], labels[:kk], locs[:kk])) if kk != B else step
-            step_k()
-            dtk, _, _ = timed(step_k, fence, 1 if prec == "fp32" else a.steps, world, dev)
-            n_steps = 1 if prec == "fp32" else a.steps
-            secondary["%s_mode_images_per_s" % prec] = round((total_images if kk == B else kk * world) * n_steps / dtk, 3)
+            n_steps = 1 if prec == "fp32" else sec_steps
+            secondary["%s_mode_images_per_s" % prec], _ = rate(step_k, n_steps, total_images if kk == B else kk * world)
             secondary["%s_mode_batch_per_gpu" % prec] = kk
-        # a point in between: only the encoder (5 % of the FLOPs; its style vector w feeds every modulation) in the split-half mode
         pipe.set_precision(a.precision)
         secondary["modes"] = ("fp32: exact fp32 MFMA (parity mode); fp16x3: split-half storage, hi*hi + hi*lo + lo*hi on the fp16 MFMA (fp32-class "
                               "accuracy); fp16x2: fp16+8 storage, hi*hi on the f16 MFMA + one block-scaled fp8 MFMA for both correction products "
@@ -388,32 +445,50 @@ def main():
             torch.cuda.synchronize()
             secondary["forced_all_gather_ms"] = round((time.perf_counter() - t0) / 5 * 1e3, 3)
 
+    units_fixed = {"fp16x2": ("fp16x3", "fp16x2"), "fp16x3": ("fp16x3", "fp16x3"), "fp16": ("fp16", "fp16"), "fp32": ("fp32", "fp32")}[a.precision]
+    img_prec = (pipe._image_precision() or a.precision) if a.config != "gan" else a.precision
+    arithmetic = {            # which algorithmic GFLOP per image run in which arithmetic (BENCH readers: this is what `value` times)
+        "resnet45_%s" % units_fixed[0]: GF_RESNET, "textvit_fp32": GF_VIT,
+        "sr_net_%s" % units_fixed[1]: round(GF_SR_TRUNK + GF_SR_PRIOR * n, 1),
+        "tspgan_prior_levels_%s" % units_fixed[1]: round((GF_GAN - GF_GAN_IMAGE_LEVEL) * n, 1),
+        "tspgan_image_only_level_%s" % img_prec: round(GF_GAN_IMAGE_LEVEL * n, 1),
+    } if a.config == "sr" else None
     out = {
         "metric": {"sr": "SR images/sec (32x512 LR -> 128x2048 SR)", "gan": "TSPGAN glyph images/sec (128x128 structure prior)",
                    "mixed": "SR images/sec (mixed-width 32x{128..512} LR, bucketed)"}[a.config],
         "value": round(total_images * a.steps / dt, 3),
         "unit": "images/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
         "ms_per_step": round(dt / a.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
-        "vs_baseline": None, "dtype": DTNAME[pdt], "data": "synthetic",
+        "vs_baseline": None, "dtype": DTNAME[pdt],
+        "data": "synthetic inputs; weights: %s" % weights_source,
         "config": {"workload": workload, "per_gpu_batch": B, "global_batch": total_images, "glyphs_per_image": n,
-                   "parallelism": "dp%d" % world,
+                   "parallelism": "dp%d" % world, "precision_mode": a.precision,
+                   "need_prior_image": bool(pipe.need_prior_image) if a.config != "gan" else True,
+                   "prior_image_precision": img_prec,
+                   "prior_image_note": ("TSPGAN's 128-px level (%.0f of %.0f GF/img) feeds only the structure image forward_batch discards: computed, in %s"
+                                        % (GF_GAN_IMAGE_LEVEL * n, gf_image, img_prec)) if a.config == "sr" else None,
+                   "gflop_per_image": round(gf_image, 1), "gflop_per_image_by_arithmetic": arithmetic,
+                   "weights": weights_source,
                    "collective": (("RCCL world of %d: " % world) + "all_gather(%s), asynchronous, overlapped with the next step"
                                   % ("uint8 BGR post-processed SR [b,128,2048,3]" if u8 else "fp32 SR outputs [b,3,128,2048]"))
                    if gather is not None else "none"},
         "roofline": roofline,
         "secondary": secondary,
     }
+    roofline.update({"all_conv_achieved": roofline["all_conv_kernels"]["achieved"], "all_conv_frac": roofline["all_conv_kernels"]["frac"],
+                     "hbm_tail_ms_per_step": roofline["hbm_tail"]["ms_per_step"], "hbm_tail_GB_per_s": roofline["hbm_tail"]["GB_per_s"],
+                     "hbm_tail_frac_of_8TBps": roofline["hbm_tail"]["frac"]})
     if a.config == "sr":
-        out["headline_note"] = ("value is measured in the %s precision mode, in the product's default configuration (check_finite on), un-instrumented. "
-                                "fp16x2 (fp16+8 storage: hi*hi on the f16 MFMA + w_lo8*x_hi8 + w_hi8*x_lo8 as one block-scaled fp8 MFMA) and fp16x3 "
-                                "(split-half storage, three f16 MFMA products) both meet the north-star parity bar (<= 1e-3, indices bit-exact; see "
-                                "parity); the plain fp16 storage mode — BASELINE configs[1]'s type, ~1e-2 deviation — and the exact fp32 mode are "
-                                "secondary.*_mode_images_per_s" % a.precision)
+        out["headline_note"] = ("value: %s mode, product defaults (check_finite on, need_prior_image on, image-only TSPGAN level in %s), un-instrumented. fp16x2 "
+                                "(fp16+8 storage: hi*hi on the f16 MFMA + w_lo8*x_hi8 + w_hi8*x_lo8 as one block-scaled fp8 MFMA) and fp16x3 (split-half, three "
+                                "f16 MFMA products) meet the north-star bar (<= 1e-3, indices bit-exact; see parity); plain fp16 (~1e-2) and exact fp32 are "
+                                "secondary.*_mode_images_per_s; secondary.images_per_s_all_levels_in_mode_precision = no level in a cheaper arithmetic" % (a.precision, img_prec))
     roofline["end_to_end_frac_of_peak"] = round(out["value"] / world * gf_image / 1e3 / peak, 4)          # of the dense fp16 (fp32-mode: fp32) MFMA peak
     if world > 1 or a.force_gather:
         out["ranks"] = {"world_size": dist.get_world_size(), "backend": dist.get_backend(),
                         "per_rank_images_per_s": [round(c_ * a.steps / t_, 2) for c_, t_ in zip(per_rank_images, per_rank_dt)]}
 
+    cpu_model, host_cores, affinity = cpu_info()
     # ---- CPU baseline (the oracle = port of the reference's CPU forward) + parity, rank 0 at N=1 only
     if rank == 0 and world == 1 and a.cpu_images > 0 and a.config == "sr":
         from oracle import marconet_oracle as O
@@ -430,8 +505,9 @@ def main():
         refs = [O.end_to_end(sde, sdg, sds, lq_c[i:i + 1], lab_c[i:i + 1], locs_c[i:i + 1]) for i in range(k)]  # batch 1, like test_sr.py:77
         cdt = time.perf_counter() - t0
         out["cpu_baseline"] = {"value": round(k / cdt, 4), "unit": "images/s", "cores": threads, "kind": "port",
-                               "sample": "%d images (batch 1 each, %d glyphs) of the same workload through oracle/marconet_oracle.py, "
-                                         "torch %s CPU fp32, %d threads" % (k, n, torch.__version__, threads)}
+                               "threads": threads, "host_cores": host_cores, "affinity_cores": affinity, "cpu_model": cpu_model,
+                               "sample": "%d strips (batch 1 each, %d glyphs) of the timed batch through oracle/marconet_oracle.py, torch %s CPU fp32, %d threads of %d cores"
+                                         % (k, n, torch.__version__, threads, host_cores)}
         # the same at batch 8 (one call) and per network (seconds per image at batch 1)
         k8 = min(8, B)
         if k8 > 1:
@@ -466,6 +542,80 @@ def main():
                 par["sr_max_abs_%s_timed_batch_without_prior_image" % a.precision] = round((y_timed_noimg[:k] - ref_sr).abs().max().item(), 6)
                 par["timed_batch_without_prior_image_equals_default"] = bool(torch.equal(y_timed, y_timed_noimg))
             par["timed_batch_strips"] = sel
+        par["weights"] = weights_source
+
+        # ---- BASELINE configs[1] / [3] / [4], driver-timed in the same line (short: `sec_steps` steps each)
+        if not a.no_secondary:
+            cfgs = {}
+            # configs[1]: batch 64 of the same strips (strip 0 is one the oracle has just recomputed)
+            k64 = min(64, B)
+            step64 = lambda: pipe.forward_batch(lq[:k64], labels[:k64], locs[:k64])       # noqa: E731
+            v64, ms64 = rate(step64, sec_steps, k64)
+            r64, _ = instrumented(step64, 1, k64 * (GF_F16_FIXED + GF_F16_PER_GLYPH * n), None, a.precision)
+            y64 = step64()
+            cfgs["configs1_batch64"] = dict(value=v64, unit="images/s", ms_per_step=ms64, steps=sec_steps, **flat_roofline(r64),
+                                            parity_sr_max_abs_strip0=round((y64[:1].cpu() - ref_sr[:1]).abs().max().item(), 6))
+            del y64
+            # configs[3]: TSPGAN alone on B x n glyphs (TSPGAN.forward: every level in the mode's arithmetic, the image is returned)
+            Ng = B * n
+            gan.set_precision(a.precision)
+            st_g, lab_g, step_g = gan_workload(Ng)
+            vg, msg = rate(step_g, sec_steps, Ng)
+            rg, _ = instrumented(step_g, 1, Ng * GF_GAN, None, a.precision)
+            kg = min(16, Ng)
+            t0 = time.perf_counter()
+            ref_g = O.tspgan_forward(sdg, st_g[:kg].cpu(), lab_g[:kg].cpu())
+            cg = time.perf_counter() - t0
+            yg = gan(styles=st_g[:kg], labels=lab_g[:kg], noise=None)
+            cfgs["configs3_gan_only"] = dict(value=vg, unit="glyph images/s", ms_per_step=msg, steps=sec_steps, glyphs_per_step=Ng, **flat_roofline(rg),
+                                             parity_image_max_abs=round((yg[0].cpu() - ref_g[0]).abs().max().item(), 6),
+                                             parity_prior64_max_abs=round((yg[1].cpu() - ref_g[1]).abs().max().item(), 6),
+                                             cpu_glyph_images_per_s=round(kg / cg, 3))
+            del st_g, lab_g, yg
+            # configs[4]: mixed widths, bucketed; parity: the narrowest strip against the reference arithmetic at its bucket width
+            lqm, wm, cm, labm, locm, gfm = mixed_workload(B)
+            stepm = lambda: pipe.forward_mixed_widths(lqm, wm, labm, locm)                 # noqa: E731
+            vm, msm = rate(stepm, sec_steps, len(wm))
+            rm, _ = instrumented(stepm, 1, gfm, None, a.precision)
+            outs = stepm()
+            bsel = min(range(len(wm)), key=lambda i: (wm[i], i))
+            wb = (wm[bsel] + 63) // 64 * 64
+            t0 = time.perf_counter()
+            with torch.no_grad():
+                lqs = lqm[bsel:bsel + 1].cpu()
+                _, _, w1 = O.encoder_forward(sde, lqs)
+                _, a64, a32 = O.tspgan_forward(sdg, w1[:1].repeat(cm[bsel], 1), labm[bsel])
+                c64 = torch.trunc(locm[bsel:bsel + 1] * 1024.0)      # the integer centres of the 512-padded run (tests/test_modules_gpu.py::test_config5_*)
+                refm = O.tspsr_forward(sds, lqs[:, :, :, :wb], [a64], [a32], (c64 + 0.5) / (2.0 * wb))
+            cmix = time.perf_counter() - t0
+            cfgs["configs4_mixed_widths"] = dict(value=vm, unit="images/s", ms_per_step=msm, steps=sec_steps, strips=len(wm), **flat_roofline(rm),
+                                                 parity_sr_max_abs_narrowest_strip=round((outs[bsel].cpu() - refm[0]).abs().max().item(), 6),
+                                                 parity_strip_width=wm[bsel], cpu_images_per_s_that_strip=round(1.0 / cmix, 4))
+            del outs, lqm
+            secondary["configs"] = cfgs
+            secondary["configs_note"] = ("BASELINE configs[1] (batch 64), [3] (TSPGAN alone, %d glyphs) and [4] (mixed widths) in this same run, %d timed steps "
+                                         "each + 1 instrumented step for the dominant kernel's fraction of 2500 TFLOP/s" % (Ng, sec_steps))
+
+        # ---- second weight regime: the trained-like synthetic checkpoints (marconet_amd/synthetic.py) through the same comparison
+        if not a.no_regimes and not weights_source.startswith("synthetic:trained"):
+            t_sde, t_sdg, t_sds, t_src = checkpoints.load_state_dicts(path="", regime="trained")
+            t_nets = checkpoints.build_networks(t_sde, t_sdg, t_sds, dev)
+            t_pipe = MarconetPipeline(*t_nets, precision=a.precision)
+            kt = min(2, k)
+            t_refs = [O.end_to_end(t_sde, t_sdg, t_sds, lq_c[i:i + 1], lab_c[i:i + 1], locs_c[i:i + 1]) for i in range(kt)]
+            t_sr = torch.cat([r["sr"] for r in t_refs])
+            t_arg = torch.cat([r["logits"] for r in t_refs]).argmax(-1)
+            reg = {"strips": sel[:kt], "oracle_sr_abs_max": round(t_sr.abs().max().item(), 4)}
+            for prec in ("fp16x2", "fp16x3", "fp32"):
+                t_pipe.set_precision(prec)
+                yk = t_pipe.forward_batch(lq[sel[:kt]].contiguous(), lab_c[:kt], locs_c[:kt])
+                lg = t_pipe.encoder(lq[sel[:kt]].contiguous())[0]
+                reg["sr_max_abs_%s" % prec] = round((yk.cpu() - t_sr).abs().max().item(), 6)
+                reg["argmax_match_%s" % prec] = round(float((lg.argmax(-1).cpu() == t_arg).float().mean()), 4)
+            par["regime_trained_like"] = reg
+            par["sr_max_abs_%s_trained_like_regime" % a.precision] = reg.get("sr_max_abs_%s" % a.precision)
+            del t_pipe, t_nets
+        par["regimes"] = "tame (default synthetic, all sr_max_abs_* above) and trained_like (heavy-tailed weights, modulation spread 1e3, SN sigma in [0.1,10])"
         par["bar"] = "north_star: <= 1e-3 max-abs on the SR output, argmax bit-exact (argmax_match == 1.0)"
         out["parity"] = par
     elif rank == 0 and world == 1 and a.cpu_images > 0 and a.config == "gan":
@@ -479,10 +629,32 @@ def main():
         ref = O.tspgan_forward(sdg, st_c, lab_c)
         cdt = time.perf_counter() - t0
         out["cpu_baseline"] = {"value": round(k / cdt, 4), "unit": "images/s", "cores": threads, "kind": "port",
-                               "sample": "%d glyphs in one TSPGAN call through oracle/marconet_oracle.py, torch %s CPU fp32, %d threads" % (k, torch.__version__, threads)}
+                               "threads": threads, "host_cores": host_cores, "affinity_cores": affinity, "cpu_model": cpu_model,
+                               "sample": "%d glyphs in one TSPGAN call through oracle/marconet_oracle.py, torch %s CPU fp32, %d threads of %d cores" % (k, torch.__version__, threads, host_cores)}
         yk = gan(styles=styles[:k], labels=glabels[:k], noise=None)
         out["parity"] = {"image_max_abs_%s" % a.precision: round((yk[0].cpu() - ref[0]).abs().max().item(), 6),
                          "prior64_max_abs_%s" % a.precision: round((yk[1].cpu() - ref[1]).abs().max().item(), 6)}
+    elif rank == 0 and world == 1 and a.cpu_images > 0 and a.config == "mixed":
+        # configs[4] stand-alone: the narrowest strip against the reference arithmetic at its bucket width, timed on the host
+        from oracle import marconet_oracle as O
+        threads = host_threads(a.cpu_threads)
+        torch.set_num_threads(threads)
+        outs = pipe.forward_mixed_widths(lq, widths, labels, locs)
+        bsel = min(range(len(widths)), key=lambda i: (widths[i], i))
+        wb = (widths[bsel] + 63) // 64 * 64
+        t0 = time.perf_counter()
+        with torch.no_grad():
+            lqs = lq[bsel:bsel + 1].cpu()
+            _, _, w1 = O.encoder_forward(sde, lqs)
+            _, a64, a32 = O.tspgan_forward(sdg, w1[:1].repeat(counts[bsel], 1), labels[bsel])
+            c64 = torch.trunc(locs[bsel:bsel + 1] * 1024.0)
+            refm = O.tspsr_forward(sds, lqs[:, :, :, :wb], [a64], [a32], (c64 + 0.5) / (2.0 * wb))
+        cdt = time.perf_counter() - t0
+        out["cpu_baseline"] = {"value": round(1.0 / cdt, 4), "unit": "images/s", "cores": threads, "kind": "port",
+                               "threads": threads, "host_cores": host_cores, "affinity_cores": affinity, "cpu_model": cpu_model,
+                               "sample": "the narrowest strip of the batch (%d px, %d glyphs) through oracle/marconet_oracle.py at its bucket width, torch %s CPU fp32, %d threads of %d cores"
+                                         % (widths[bsel], counts[bsel], torch.__version__, threads, host_cores)}
+        out["parity"] = {"sr_max_abs_%s_narrowest_strip" % a.precision: round((outs[bsel].cpu() - refm[0]).abs().max().item(), 6), "strip_width": widths[bsel]}
 
     if rank == 0:
         print(json.dumps(out))

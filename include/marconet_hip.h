@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define MNET_ABI_VERSION 3
+#define MNET_ABI_VERSION 4
 
 /* MNET_F16X2 ("split half", the storage of the fp16x3 precision mode): every logical element is a pair of halves (hi, lo),
  * value = float(hi) + float(lo), hi = f16(v), lo = f16(v - hi): ~22 significant bits at fp16 MFMA rates (x*w is evaluated as
@@ -325,6 +325,12 @@ int mnet_conv3x3_rgb(const void* x, int32_t dtype, int32_t n, int32_t h, int32_t
  * script hands to cv2.imwrite) or uint8 (dst_u8 != 0: cv2's float→uchar conversion, round half to even) — 4x fewer bytes
  * for the device→host copy and the multi-GPU all-gather (SURVEY.md §8f NEXT-1) */
 int mnet_sr_postprocess(const void* src, int32_t src_dtype, void* dst, int32_t dst_u8, int64_t npix, int32_t c_ld, void* stream);
+
+/* Finiteness guard of the half-range precision modes (the role `torch.isfinite(y).all()` would play after test_sr.py:197 — the
+ * reference has no such check because its fp32 activations cannot overflow): *flag (int32, device) is set to 0 and then to 1 by any
+ * thread that finds an element of x (n elements, MNET_F32 or MNET_F16) that is inf or NaN.  One streaming read of x, no atomics
+ * (every writer stores the same value), no synchronisation: the caller reads the flag back when it consumes the result. */
+int mnet_nonfinite_flag(const void* x, int32_t dtype, int64_t n, int32_t* flag, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * One-time weight packing on the device: from the checkpoint's tensors to the layouts above, without PyTorch

@@ -9,7 +9,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("MARCONET_HIP_LIB", os.path.join(_HERE, "lib", "libmarconet_hip.so"))
 
-ABI_VERSION = 3               # MNET_ABI_VERSION of include/marconet_hip.h this binding was written against
+ABI_VERSION = 4               # MNET_ABI_VERSION of include/marconet_hip.h this binding was written against
 MNET_F32, MNET_F16, MNET_F16X2, MNET_F16M = 0, 1, 2, 3
 ACT_NONE, ACT_RELU, ACT_LRELU, ACT_LRELU_SQRT2, ACT_TANH, ACT_GELU, ACT_SIGMOID = range(7)
 ALGO_AUTO, ALGO_REG_STAGED, ALGO_LDS_DMA, ALGO_SKINNY, ALGO_DMA_CFG0, ALGO_STRIP_CFG0, ALGO_DMA_CFG16, ALGO_FLAG_ONE_TILE = 0, 1, 2, 3, 16, 32, 64, 256
@@ -78,6 +78,7 @@ SYMBOLS = {
     "mnet_torgb": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "mnet_conv3x3_rgb": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p]),
     "mnet_sr_postprocess": (c_int, [c_void_p, c_int, c_void_p, c_int, c_i64, c_int, c_void_p]),
+    "mnet_nonfinite_flag": (c_int, [c_void_p, c_int, c_i64, c_void_p, c_void_p]),
     "mnet_pack_weights": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_float, c_int, c_int, c_int, c_void_p,
                                   c_void_p, c_void_p]),
     "mnet_pack_wsq": (c_int, [c_void_p, c_int, c_int, c_int, c_float, c_void_p, c_void_p]),

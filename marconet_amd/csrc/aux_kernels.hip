@@ -942,6 +942,41 @@ extern "C" int mnet_sr_postprocess(const void* src, int32_t src_dtype, void* dst
     return MNET_OK;
 }
 
+// ============================================================================ finiteness flag
+// One streaming read (16 bytes per lane and trip): an element is non-finite iff its exponent field is all ones.  No atomics — every
+// thread that finds one stores the same 1; the flag was zeroed on the stream just before.
+template <typename T>
+__global__ void __launch_bounds__(256) nonfinite_flag_kernel(const T* __restrict__ x, long long n, int* __restrict__ flag) {
+    constexpr int N = 16 / (int)sizeof(T);
+    const long long nv = n / N;
+    bool bad = false;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < nv; i += (long long)gridDim.x * 256) {
+        const u32x4 v = ldg16(x + i * N);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            if constexpr (sizeof(T) == 4) bad |= (v[j] & 0x7f800000u) == 0x7f800000u;
+            else bad |= (v[j] & 0x7c00u) == 0x7c00u || (v[j] & 0x7c000000u) == 0x7c000000u;
+        }
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0)                  // the tail (< 16 bytes)
+        for (long long i = nv * N; i < n; ++i) { const float f = (float)x[i]; bad |= !(fabsf(f) <= 3.0e38f); }
+    if (bad) *flag = 1;
+}
+
+extern "C" int mnet_nonfinite_flag(const void* x, int32_t dtype, int64_t n, int32_t* flag, void* stream) {
+    MNET_CHECK_ARG(x && flag && n > 0, "nonfinite_flag: bad args");
+    MNET_CHECK_ARG(dtype == MNET_F32 || dtype == MNET_F16, "nonfinite_flag: MNET_F32 or MNET_F16 expected");
+    MNET_CHECK_ALIGN(aligned16(x), "nonfinite_flag: x must be 16-byte aligned");
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    if (hipMemsetAsync(flag, 0, sizeof(int32_t), st) != hipSuccess) return mnet_fail(MNET_E_LAUNCH, "nonfinite_flag: hipMemsetAsync failed");
+    const long long nv = n / (dtype == MNET_F32 ? 4 : 8);
+    const int grid = (int)((nv + 255) / 256 < 4096 ? (nv + 255) / 256 > 0 ? (nv + 255) / 256 : 1 : 4096);
+    if (dtype == MNET_F16) hipLaunchKernelGGL(nonfinite_flag_kernel<f16>, dim3(grid), dim3(256), 0, st, (const f16*)x, (long long)n, flag);
+    else hipLaunchKernelGGL(nonfinite_flag_kernel<float>, dim3(grid), dim3(256), 0, st, (const float*)x, (long long)n, flag);
+    MNET_LAUNCH_CHECK("nonfinite_flag");
+    return MNET_OK;
+}
+
 // ============================================================================ ToRGB (StyleGAN skip branch)
 // ToRGB.forward (models/networks.py:313-321): a MODULATED 1x1 conv to 3 channels without demodulation, + bias, + the bilinearly
 // up-sampled RGB of the level below, then tanh.  Through the implicit-GEMM kernel this is a register-staged launch with a style

@@ -558,6 +558,7 @@ static int conv_prepare(const mnet_conv_desc* d, int32_t algo, ConvArgs& a) {
     a.in_swish = d->in_swish; a.act = d->act; a.res_mod = d->res_mod;
     const int bk = d->dtype == MNET_F32 ? 32 : 64;
     a.ktiles = (a.K + bk - 1) / bk; a.tilesC = 0; a.ntiles = 0;
+    a.howo_shift = a.wo_shift = -1;      // "not a power of two" until an LDS-DMA launcher says otherwise (0 would read as a shift by 0)
     a.center_tap = (d->kh / 2) * d->kw + d->kw / 2;
     a.center_tpx = (d->kh / 2) * d->w + d->kw / 2;
     if (a.x1_center) {

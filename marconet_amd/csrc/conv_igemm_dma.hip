@@ -156,7 +156,7 @@ __global__ void __launch_bounds__(WC * WP * 64, WC * WP / 4) conv_dma_kernel(con
             const int px = ((n - n_first) * p.h + ih0) * p.w + iw0;
             const int vw = min(xvwj, p.w);
             // taps enumerated t = r*kw + q: columns q in [qlo, qhi), rows r in [rlo, rhi)
-            const int qlo = max(0, -iw0), qhi = min(p.kw, vw - iw0), rlo = max(0, -ih0), rhi = min(p.kh, p.h - ih0);
+            const int qlo = min(p.kw, max(0, -iw0)), qhi = min(p.kw, vw - iw0), rlo = min(p.kh, max(0, -ih0)), rhi = min(p.kh, p.h - ih0);   // (clamped: a padding beyond the filter must not reach the shifts below)
             const unsigned cm = ((1u << max(qhi, 0)) - 1u) & ~((1u << qlo) - 1u);                     // kw <= 8; qhi <= qlo gives 0
             const int sh_hi = max(rhi, 0) * p.kw, sh_lo = rlo * p.kw;                                    // <= 32 (eligibility: kh * kw <= 32)
             const unsigned rr = (sh_hi >= 32 ? rowrep : rowrep & ((1u << sh_hi) - 1u)) & (sh_lo >= 32 ? 0u : ~((1u << sh_lo) - 1u));

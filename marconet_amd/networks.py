@@ -15,7 +15,7 @@ import os
 import torch
 import torch.nn as nn
 
-from . import ops
+from . import _lib, ops
 from .glyphs import GlyphTables
 from .packing import (PRECISIONS, SPLIT_DTYPE, PackCache, is_split, default_precision, equal_linear_scale, pack_conv_weight,
                       pack_linear_weight, pack_vec, pack_wsq, padded_cout, rgb_pad, torch_dtype)
@@ -427,7 +427,7 @@ class TSPSRNet(nn.Module, _Precision):
             pk[name + ".norm2"] = (f(m.norm2.weight), f(m.norm2.bias))
             if hasattr(m, "conv_out"):
                 pk[name + ".conv_out"] = dict(w=pack_conv_weight(m.conv_out.weight.detach(), dtype), b=f(m.conv_out.bias))
-                if dtype != torch.float32 and m.conv_out.weight.is_cuda:
+                if dtype != torch.float32:
                     # round 4: h + conv_out(x) (models/networks.py:514-515) folded into conv2's k-loop — one weight tensor [cout][3][3][C + Cin]
                     # whose second part is the 1x1 skip weight at the centre tap (MNET_CONV_ALGO_FLAG_X1_CENTER), one bias.  Layout plumbing only:
                     # the spectral-norm fold of conv2 is the library's (fp32 pack), the skip weights are copied into a zero tensor
@@ -471,8 +471,13 @@ class TSPSRNet(nn.Module, _Precision):
 
     def _res_block(self, pk, name, x, valid_w=None, norm1_affine=None):
         """ResTextBlockV2 (networks.py:506-516): GN statistics → one elementwise normalise+swish pass → conv; the skip
-        (+1x1 conv_out) rides in the second conv's epilogue.  ``norm1_affine``: (scale, shift) of norm1 when the producer
-        of x already has them (the AdaIN kernel for the fuse blocks)."""
+        rides in the second conv — as extra K at the centre tap when the block has a 1x1 conv_out (the fuse blocks), as the
+        epilogue's residual otherwise.  ``norm1_affine``: (scale, shift) of norm1 when the producer of x already has them (the
+        AdaIN kernel for the fuse blocks).
+        Masked-column contract (``valid_w``): the folded form reads x like every conv input — zeros at columns >= valid_w[n] — so
+        there its output is conv2(h) + bias only, while the two-launch form adds conv_out(x) of whatever x holds there.  Both are
+        outside the glyph's window: nothing downstream reads them (the scale / shift convs mask the same columns, the scatter
+        writes columns < valid_w only), and the AdaIN kernel writes zeros there anyway."""
         s1, h1 = norm1_affine if norm1_affine is not None else ops.groupnorm_affine(x, *pk[name + ".norm1"], 1e-6, valid_w)
         xs = ops.affine_act(x, s1, h1, swish=True)              # GN apply + swish once per element
         h = self._c(pk, name + ".conv1", xs, valid_w=valid_w)
@@ -482,7 +487,13 @@ class TSPSRNet(nn.Module, _Precision):
         skip = x
         if (name + ".conv2+out") in pk and _FOLD_SKIP:
             L = pk[name + ".conv2+out"]       # the 1x1 skip conv as extra K of conv2: no separate launch, no residual read in the epilogue
-            return ops.conv2d(h, L["w"], L["cout"], 3, 3, (1, 1), (1, 1), x1=x, bias=L["b"], valid_w=valid_w, x1_center=True)
+            try:
+                return ops.conv2d(h, L["w"], L["cout"], 3, 3, (1, 1), (1, 1), x1=x, bias=L["b"], valid_w=valid_w, x1_center=True)
+            except _lib.MarconetHipError as e:
+                # only the LDS-DMA kernels walk a second source at one tap; a launch they do not take (MNET_E_ARG from the planner, nothing
+                # was enqueued) falls back to the two-launch form below instead of failing the forward
+                if "X1_CENTER" not in str(e):
+                    raise
         if (name + ".conv_out") in pk:
             co = pk[name + ".conv_out"]
             skip = ops.conv2d(x, co["w"], co["b"].numel(), bias=co["b"])

@@ -18,7 +18,7 @@ from .packing import MX_DTYPE, SPLIT_DTYPE, is_split, mx_weight_rows, new_tensor
 __all__ = ["conv2d", "linear", "nchw_to_nhwc", "nhwc_to_nchw", "upsample2x", "affine_act", "groupnorm_affine",
            "adain_crop_concat", "adain_crop_concat_gn", "glyph_scatter_affine", "layernorm", "token_mix", "attention", "pixelnorm",
            "embed_gather", "demod", "argmax_rows", "convert", "fused_bias_act", "sr_postprocess", "conv3x3_rgb", "torgb", "stats",
-           "pack_weights", "pack_wsq", "gather_rows", "style_rows",
+           "pack_weights", "pack_wsq", "gather_rows", "style_rows", "nonfinite_flag",
            "ACT_NONE", "ACT_RELU", "ACT_LRELU", "ACT_LRELU_SQRT2", "ACT_TANH", "ACT_GELU", "ACT_SIGMOID"]
 
 
@@ -469,6 +469,18 @@ def sr_postprocess(y_nhwc, u8=True):
     _lib.check(lib.mnet_sr_postprocess(_p(y_nhwc), _dt(y_nhwc), _p(out), 1 if u8 else 0, b * h * w, c_ld, _stream()),
                "mnet_sr_postprocess")
     return out
+
+
+def nonfinite_flag(x, out=None):
+    """mnet_nonfinite_flag: int32 [1] device tensor (``out``: a one-element int32 view to write into), 1 iff the fp32 / fp16 tensor
+    ``x`` holds an inf or NaN (no synchronisation here)"""
+    lib = _lib.load()
+    _need_cuda(x, out)
+    flag = torch.empty((1,), dtype=torch.int32, device=x.device) if out is None else out
+    if flag.dtype != torch.int32 or flag.numel() != 1:
+        raise TypeError("nonfinite_flag: out must be one int32 element")
+    _lib.check(lib.mnet_nonfinite_flag(_p(x), _dt(x), x.numel(), _p(flag), _stream()), "mnet_nonfinite_flag")
+    return flag
 
 
 @_plumbing

@@ -311,7 +311,7 @@ def equal_linear_scale(in_channels, lr_mul):
 # structure and the non-tensor leaves as JSON metadata, and a SHA-256 of each holder's parameters so that a blob is never
 # attached to different weights.
 PACK_FORMAT = "marconet_amd.packed.v2"
-PACK_LAYOUT = 5        # bump whenever any holder's _build() changes what it emits (keys, padding, layouts): a blob written by a
+PACK_LAYOUT = 6        # (6: ResTextBlockV2 emits '<block>.conv2+out', round 4; holders write every precision they have packed for) bump whenever any holder's _build() changes what it emits (keys, padding, layouts): a blob written by a
                        # different _build must not attach (it would fail with a KeyError mid-forward, or be read with another layout)
 
 

@@ -74,7 +74,8 @@ class MarconetPipeline:
         """half-range modes (fp16 / fp16x3 / fp16x2 store |activation| < 65504): an overflow turns into NaN on its way through the
         GroupNorm statistics of the following layers (and the last layer writes an infinite pre-activation as NaN instead of
         tanh's +-1), so the SR result carries it; one flag is read back per batch."""
-        if self._checks() and self._finite is not None and not bool(self._finite):
+        # _finite: int32 flags written by mnet_nonfinite_flag (1 = inf / NaN found) — ONE device→host copy, tested on the host
+        if self._checks() and self._finite is not None and any(self._finite.cpu().tolist()):
             raise FloatingPointError("marconet_amd: non-finite SR output in %s mode (activations beyond the fp16 range 65504?) — use "
                                      "precision='fp32' for these weights" % self.precision)
 
@@ -117,10 +118,10 @@ class MarconetPipeline:
             p64 = p32 = None
         if output != "u8_bgr" and not return_nhwc:
             y = self.sr.forward_packed(lq, p64, p32, counts, counts, locs, nchw_out=True, tables=tables)   # test_sr.py:197
-            self._finite = torch.isfinite(y).all() if self._checks() else None   # device-side flag: no synchronisation here
+            self._finite = ops.nonfinite_flag(y) if self._checks() else None    # device-side flag (mnet_nonfinite_flag): no synchronisation here
             return y
         y = self.sr.forward_packed(lq, p64, p32, counts, counts, locs, tables=tables)
-        self._finite = torch.isfinite(y).all() if self._checks() else None
+        self._finite = ops.nonfinite_flag(y) if self._checks() else None
         if output == "u8_bgr":                                           # test_sr.py:198-200 fused: [B,128,2048,3] uint8
             return ops.sr_postprocess(y, u8=True)
         return y if return_nhwc else ops.nhwc_to_nchw(y, c=3)
@@ -167,8 +168,9 @@ class MarconetPipeline:
             _, p64, p32 = tg.forward_nhwc(w.index_select(0, img_of).contiguous(), lab, need_image=self.need_prior_image,
                                           image_precision=self._image_precision())
         out = [None] * B
-        flags = []
-        for wb in sorted(set(widths)):
+        buckets = sorted(set(widths))
+        flags = torch.empty((len(buckets),), dtype=torch.int32, device=dev) if self._checks() else None     # one finiteness flag per bucket
+        for kb, wb in enumerate(buckets):
             idx = [b for b in range(B) if widths[b] == wb]
             gsel = [g for b in idx for g in range(starts[b], starts[b + 1])]
             cb = [counts[b] for b in idx]
@@ -185,11 +187,11 @@ class MarconetPipeline:
             else:
                 a = c = None
             y = self.sr.forward_packed(lq_b, a, c, cb, cb, None, nchw_out=True, tables=tables)
-            if self._checks():
-                flags.append(torch.isfinite(y).all())
+            if flags is not None:
+                ops.nonfinite_flag(y, out=flags[kb:kb + 1])
             for k, b in enumerate(idx):
                 out[b] = y[k]
-        self._finite = torch.stack(flags).all() if flags else None
+        self._finite = flags
         self._raise_if_not_finite()
         return out
 
@@ -333,14 +335,18 @@ class GraphedForward:
 
     def raise_if_not_finite(self):
         """reads this graph's own flag (one device→host synchronisation) — for callers that replay with check=False and test later"""
-        if self._flag is not None and not bool(self._flag):
+        if self._flag is None:
+            raise RuntimeError("GraphedForward: this graph was captured with the finiteness check off (check_finite=False, or the fp32 mode): "
+                               "there is no flag to read — capture with MarconetPipeline(check_finite=True)")
+        if any(self._flag.cpu().tolist()):
             raise FloatingPointError("marconet_amd: non-finite SR output in %s mode (activations beyond the fp16 range 65504?) — use "
                                      "precision='fp32' for these weights" % self.pipe.precision)
 
     @torch.no_grad()
     def __call__(self, lq, labels, locs, check=None):
         """``check``: None = as the pipe was configured at capture (on for the half-range modes: one flag read back, i.e. one
-        synchronisation per replay); False = no read-back on the latency path — call raise_if_not_finite() when the output is consumed"""
+        synchronisation per replay); False = no read-back on the latency path — call raise_if_not_finite() when the output is consumed;
+        True on a graph captured WITHOUT the flag raises RuntimeError (a check that cannot happen must not pass silently)"""
         from .glyphs import GlyphTables
         counts = [int(l.shape[0]) for l in labels]
         if counts != self.counts or tuple(lq.shape) != tuple(self.lq.shape):

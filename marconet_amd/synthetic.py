@@ -64,17 +64,54 @@ def _t(a):
     return torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32))
 
 
+# ----------------------------------------------------------------------------- weight regimes
+# "tame" (default; every golden fixture): near-Gaussian / uniform weights of one scale per tensor — activations O(1) everywhere.
+# "trained": a second seeded regime shaped like what training leaves behind, so that the parity margin of the
+# half-range modes is reported on something other than the friendly strips:
+#   * heavy-tailed conv weights: every element N(0,1)·exp(TAIL·N(0,1)) (log-normal magnitude mixing: kurtosis ~ 20 at TAIL = 0.6) and a
+#     log-normal gain per OUTPUT channel (exp(ROW·N(0,1))), renormalised to the tame regime's variance — a few large taps per filter,
+#     channels of very different magnitude inside one 32-channel storage block;
+#   * StyleGAN-scale modulation: ``modulation.bias`` log-uniform over [10^-1.5, 10^+1.5] (a per-channel spread of 10^3 in the
+#     style that multiplies the activations) instead of 1 +- 0.1;
+#   * spectral-norm convs stored at sigma(weight_orig) log-uniform in [0.1, 10] (the fold divides by sigma: the effective weight keeps
+#     spectral norm 1 but weight_orig, u and v live at very different scales per layer);
+#   * GroupNorm / LayerNorm gains log-normal (a spread of x0.4 ... x2.5 around the median; TSPSRNet's GroupNorms around a median of 2.5,
+#     which gives the SR output the tame regime's range), biases three times wider.
+# The regime is still numerically sane in fp32 (finite, tanh not saturated) — that is checked where it is used.
+REGIMES = ("tame", "trained")
+_TAIL, _ROW = 0.6, 0.5
+
+
+def _check_regime(regime):
+    if regime not in REGIMES:
+        raise ValueError("regime must be one of %s" % ", ".join(REGIMES))
+    return regime == "trained"
+
+
+def _heavy(seed, key, shape):
+    """N(0,1)·exp(TAIL·z) per element times exp(ROW·z') per row (dim 0), scaled back to unit variance (fp64)"""
+    z = normal(seed, key, shape) * np.exp(_TAIL * normal(seed, key + "#tail", shape))
+    row = np.exp(_ROW * normal(seed, key + "#row", (shape[0],))).reshape((shape[0],) + (1,) * (len(shape) - 1))
+    z = z * row
+    return z / math.sqrt(float(np.mean(z * z)))
+
+
+def _loguniform(seed, key, shape, lo, hi):
+    return np.exp(math.log(lo) + uniform01(seed, key, shape) * (math.log(hi) - math.log(lo)))
+
+
 # ----------------------------------------------------------------------------- encoder checkpoint
 _RESNET_LAYERS = [(32, 3), (64, 4), (128, 6), (256, 6), (512, 3)]   # models/resnet.py:74 [3,4,6,6,3]
 
 
-def make_encoder_state_dict(seed=1234, resnet_gain=None, input_gain=1.0, cls_gain=3.0):
+def make_encoder_state_dict(seed=1234, resnet_gain=None, input_gain=1.0, cls_gain=3.0, regime="tame"):
     """Keys of ``TextContextEncoderV2`` (models/networks.py:27-45).
     Stress variants (tests/test_stress_gpu.py): ``resnet_gain=1.0`` = the reference's own initialisation of every ResNet conv
     (models/resnet.py:45-48: features of std ~78, |max| ~610); ``input_gain`` multiplies conv1 — the BN-free,
     bias-free ReLU stack is positively homogeneous, so it scales every ResNet activation by that factor; ``cls_gain=1.0`` leaves
     near-ties among the 6736 logits (top-2 gaps down to 1e-4 and below)."""
     sd = {}
+    trained = _check_regime(regime)
 
     def conv_w(key, cout, cin, k, gain):
         # reference init is N(0, sqrt(2/(k*k*cout))) (models/resnet.py:45-48); gain<1 keeps the
@@ -82,7 +119,7 @@ def make_encoder_state_dict(seed=1234, resnet_gain=None, input_gain=1.0, cls_gai
         if resnet_gain is not None:
             gain = resnet_gain
         std = gain * math.sqrt(2.0 / (k * k * cout))
-        sd[key] = _t(normal(seed, key, (cout, cin, k, k)) * std)
+        sd[key] = _t((_heavy(seed, key, (cout, cin, k, k)) if trained else normal(seed, key, (cout, cin, k, k))) * std)
 
     conv_w("resnet.conv1.weight", 32, 3, 3, 1.0)
     if input_gain != 1.0:
@@ -105,6 +142,10 @@ def make_encoder_state_dict(seed=1234, resnet_gain=None, input_gain=1.0, cls_gai
             sd[key + ".bias"] = _t((uniform01(seed, key + ".bias", (out_f,)) * 2 - 1) * b)
 
     def layernorm(key, n):
+        if trained:
+            sd[key + ".weight"] = _t(np.exp(0.45 * normal(seed, key + ".weight", (n,))))
+            sd[key + ".bias"] = _t(0.3 * normal(seed, key + ".bias", (n,)))
+            return
         sd[key + ".weight"] = _t(1.0 + 0.1 * normal(seed, key + ".weight", (n,)))
         sd[key + ".bias"] = _t(0.1 * normal(seed, key + ".bias", (n,)))
 
@@ -149,9 +190,13 @@ def _apply_outliers(sd, outliers, skip=()):
         sd[key][idx] *= float(gain)
 
 
-def make_gan_state_dict(seed=1234, outliers=None):
+def make_gan_state_dict(seed=1234, outliers=None, regime="tame"):
     """Keys of ``TSPGAN`` (models/networks.py:51-164), all under ``TextGenerator.``"""
     sd = {}
+    trained = _check_regime(regime)
+    wn = (lambda key, shape: _heavy(seed, key, shape)) if trained else (lambda key, shape: normal(seed, key, shape))
+    # modulation bias: 1 +- 0.1, or — trained — log-uniform over three decades (the style multiplies the ACTIVATIONS on this implementation)
+    mb = (lambda key, n: _loguniform(seed, key, (n,), 10.0 ** -1.5, 10.0 ** 1.5)) if trained else (lambda key, n: 1.0 + 0.1 * normal(seed, key, (n,)))
     P = "TextGenerator."
     for i in range(1, 9):
         k = P + "style_mlp.%d" % i
@@ -163,16 +208,16 @@ def make_gan_state_dict(seed=1234, outliers=None):
 
     def styled(prefix, cin, cout):
         sd[prefix + ".bias"] = _t(0.1 * normal(seed, prefix + ".bias", (1, cout, 1, 1)))
-        sd[prefix + ".conv.weight"] = _t(normal(seed, prefix + ".conv.weight", (1, cout, cin, 3, 3)))
-        sd[prefix + ".conv.modulation.weight"] = _t(normal(seed, prefix + ".conv.modulation.weight", (cin, 512)))
-        sd[prefix + ".conv.modulation.bias"] = _t(1.0 + 0.1 * normal(seed, prefix + ".conv.modulation.bias", (cin,)))
+        sd[prefix + ".conv.weight"] = _t(wn(prefix + ".conv.weight", (cout, cin, 3, 3)).reshape(1, cout, cin, 3, 3))
+        sd[prefix + ".conv.modulation.weight"] = _t(wn(prefix + ".conv.modulation.weight", (cin, 512)))
+        sd[prefix + ".conv.modulation.bias"] = _t(mb(prefix + ".conv.modulation.bias", cin))
         sd[prefix + ".activate.bias"] = _t(0.1 * normal(seed, prefix + ".activate.bias", (cout,)))
 
     def torgb(prefix, cin):
         sd[prefix + ".bias"] = _t(0.1 * normal(seed, prefix + ".bias", (1, 3, 1, 1)))
-        sd[prefix + ".conv.weight"] = _t(normal(seed, prefix + ".conv.weight", (1, 3, cin, 1, 1)))
-        sd[prefix + ".conv.modulation.weight"] = _t(normal(seed, prefix + ".conv.modulation.weight", (cin, 512)))
-        sd[prefix + ".conv.modulation.bias"] = _t(1.0 + 0.1 * normal(seed, prefix + ".conv.modulation.bias", (cin,)))
+        sd[prefix + ".conv.weight"] = _t(wn(prefix + ".conv.weight", (3, cin, 1, 1)).reshape(1, 3, cin, 1, 1))
+        sd[prefix + ".conv.modulation.weight"] = _t(wn(prefix + ".conv.modulation.weight", (cin, 512)))
+        sd[prefix + ".conv.modulation.bias"] = _t(mb(prefix + ".conv.modulation.bias", cin))
 
     styled(P + "conv1", 512, 512)
     torgb(P + "to_rgb1", 512)
@@ -187,6 +232,9 @@ def make_gan_state_dict(seed=1234, outliers=None):
 
 
 # ----------------------------------------------------------------------------- SR checkpoint
+_SR_TRAINED = [False]
+_GN_MEDIAN = [2.5]      # trained regime: GroupNorm gains of median 2.5 — calibrated so that the SR output spans the tanh range like the tame
+                          # regime's (|sr| std 0.37, max 0.9; at median 1 the heavy-tailed spectral-norm convs leave it at std 0.16)
 _SN_ROW_GAIN = {}      # make_sr_state_dict(outliers=...): weight_orig rows scaled BEFORE the power iteration (sigma stays the true spectral norm)
 
 
@@ -196,11 +244,25 @@ def _sn_conv(sd, seed, key, cout, cin, k=3, iters=40):
     weight_orig / (uᵀ · W_mat · v).  u, v are power-iterated here so sigma is the spectral norm."""
     fan_in = cin * k * k
     bound = 1.0 / math.sqrt(fan_in)
-    w = (uniform01(seed, key + ".weight_orig", (cout, cin, k, k)) * 2 - 1) * bound
+    trained = _SR_TRAINED[0]
+    if trained:                         # heavy-tailed, of the uniform init's variance (bound^2 / 3)
+        w = _heavy(seed, key + ".weight_orig", (cout, cin, k, k)) * (bound / math.sqrt(3.0))
+    else:
+        w = (uniform01(seed, key + ".weight_orig", (cout, cin, k, k)) * 2 - 1) * bound
     if key + ".weight_orig" in _SN_ROW_GAIN:
         row, gain = _SN_ROW_GAIN[key + ".weight_orig"]
         w[row] *= float(gain)
-    sd[key + ".bias"] = _t((uniform01(seed, key + ".bias", (cout,)) * 2 - 1) * bound)
+    if trained:                         # stored at sigma(weight_orig) log-uniform in [0.1, 10]: two SVD-free steps — the true sigma by a float64 power
+        wm0 = np.ascontiguousarray(w.reshape(cout, -1).astype(np.float32)).astype(np.float64)           # iteration, then one rescale
+        u0 = normal(seed, key + "#sigma", (cout,))
+        for _ in range(iters):
+            v0 = wm0.T @ u0; v0 /= np.linalg.norm(v0) + 1e-12
+            u0 = wm0 @ v0; u0 /= np.linalg.norm(u0) + 1e-12
+        sigma = float(u0 @ (wm0 @ v0))
+        w = w * (float(_loguniform(seed, key + "#target", (1,), 0.1, 10.0)[0]) / sigma)
+        sd[key + ".bias"] = _t(0.08 * normal(seed, key + ".bias", (cout,)))
+    else:
+        sd[key + ".bias"] = _t((uniform01(seed, key + ".bias", (cout,)) * 2 - 1) * bound)
     sd[key + ".weight_orig"] = _t(w)
     wm = np.ascontiguousarray(w.reshape(cout, -1).astype(np.float32)).astype(np.float64)
     u = normal(seed, key + ".weight_u", (cout,))
@@ -216,6 +278,10 @@ def _sn_conv(sd, seed, key, cout, cin, k=3, iters=40):
 
 
 def _gn(sd, seed, key, c):
+    if _SR_TRAINED[0]:
+        sd[key + ".weight"] = _t(_GN_MEDIAN[0] * np.exp(0.45 * normal(seed, key + ".weight", (c,))))
+        sd[key + ".bias"] = _t(0.3 * normal(seed, key + ".bias", (c,)))
+        return
     sd[key + ".weight"] = _t(1.0 + 0.1 * normal(seed, key + ".weight", (c,)))
     sd[key + ".bias"] = _t(0.1 * normal(seed, key + ".bias", (c,)))
 
@@ -227,14 +293,18 @@ def _resblock(sd, seed, key, cin, cout):
     _sn_conv(sd, seed, key + ".conv2", cout, cout)
     if cin != cout:
         bound = 1.0 / math.sqrt(cin)
-        sd[key + ".conv_out.weight"] = _t((uniform01(seed, key + ".conv_out.weight", (cout, cin, 1, 1)) * 2 - 1) * bound)
+        if _SR_TRAINED[0]:
+            sd[key + ".conv_out.weight"] = _t(_heavy(seed, key + ".conv_out.weight", (cout, cin, 1, 1)) * (bound / math.sqrt(3.0)))
+        else:
+            sd[key + ".conv_out.weight"] = _t((uniform01(seed, key + ".conv_out.weight", (cout, cin, 1, 1)) * 2 - 1) * bound)
         sd[key + ".conv_out.bias"] = _t((uniform01(seed, key + ".conv_out.bias", (cout,)) * 2 - 1) * bound)
 
 
-def make_sr_state_dict(seed=1234, outliers=None):
+def make_sr_state_dict(seed=1234, outliers=None, regime="tame"):
     """Keys of ``TSPSRNet`` (models/networks.py:328-409).  ``outliers``: see _apply_outliers; a ``*.weight_orig`` entry scales that output
     row of a spectral-normalised conv before its u / v are power-iterated."""
     sd = {}
+    _SR_TRAINED[0] = _check_regime(regime)
     _SN_ROW_GAIN.clear()
     _SN_ROW_GAIN.update({k: v for k, v in (outliers or {}).items() if k.endswith(".weight_orig")})
     D = 256
@@ -264,6 +334,7 @@ def make_sr_state_dict(seed=1234, outliers=None):
     missing = [k for k in _SN_ROW_GAIN if k not in sd]
     _apply_outliers(sd, outliers, skip=tuple(_SN_ROW_GAIN))
     _SN_ROW_GAIN.clear()
+    _SR_TRAINED[0] = False
     if missing:
         raise KeyError("outlier keys %s not in this state_dict" % missing)
     return sd

@@ -49,6 +49,17 @@ def ckpts():
 
 
 @pytest.fixture(scope="session")
+def harness_weights():
+    """the weight sets the regime harness (tests/test_regimes_gpu.py) runs: the trained-like synthetic regime always, and the reference's
+    REAL checkpoints when MARCONET_CKPT_DIR holds them (marconet_amd/checkpoints.py; test_sr.py:43-51) — the same comparison, unchanged"""
+    from marconet_amd import checkpoints
+    sets = {"trained_like": checkpoints.load_state_dicts(path="", regime="trained")}
+    if checkpoints.checkpoint_dir() is not None:
+        sets["real_checkpoints"] = checkpoints.load_state_dicts()
+    return sets
+
+
+@pytest.fixture(scope="session")
 def golden():
     import numpy as np
     return dict(np.load(os.path.join(ROOT, "tests", "golden", "golden_v1.npz")))

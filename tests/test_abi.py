@@ -30,7 +30,7 @@ def test_library_exports_every_declared_symbol():
         assert n in _lib.SYMBOLS, "header symbol %s has no ctypes binding" % n
         assert getattr(lib, n) is not None
     assert set(_lib.SYMBOLS) == set(names)
-    assert lib.mnet_abi_version() == _lib.ABI_VERSION == 3
+    assert lib.mnet_abi_version() == _lib.ABI_VERSION == 4
 
 
 def test_conv_desc_layout_matches_c():

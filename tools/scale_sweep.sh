@@ -4,7 +4,9 @@
 # For N in {1, 2, 4, 8} (as many as are visible): BASELINE configs[2] (`bench.py --batch 128`, weak scaling: 128 strips per GPU, the
 # uint8 all-gather of every step inside the timed region) and configs[4] (`--config mixed`, work-balanced shards, bucketed widths),
 # then the gathered-vs-single-GPU bit-equality test (tests/test_multigpu_gpu.py, parametrised over 2 / 4 / 8 ranks).
-# Output: one JSON line per run under <outdir>/ and a 4-row table per config: N, images/s, per-rank images/s, RCCL world size, scaling vs N = 1.
+# Output: one JSON line per run under <outdir>/, a 4-row table per config (N, images/s, per-rank images/s, RCCL world size, ratio to N x the
+# N = 1 rate) and <outdir>/SCALE_manual.json — ONE record of the same content (per config: the rows; the equality test's result; GPUs visible;
+# commit; UTC time), shaped so that it can stand where the driver's SCALE_rNN.json stands the day a node exists, without edits.
 set -uo pipefail
 OUT="${1:-gpurun_out/scale_sweep}"; mkdir -p "$OUT"
 export HSA_ENABLE_IPC_MODE_LEGACY=0 TMPDIR=/tmp
@@ -41,6 +43,27 @@ for n in (1, 2, 4, 8):
 print("config %-6s  N   images/s   per-rank images/s                         RCCL world   vs N x (N=1)" % name)
 for n, v, pr, w, eff in rows:
     print("               %d   %8.1f   %-42s %-10s   %.3f" % (n, v, " ".join("%.1f" % x for x in pr), w, eff))
+json.dump([{"n_gpus": n, "value": v, "unit": "images/s", "per_rank_images_per_s": pr, "rccl_world_size": w, "ratio_to_N_times_N1": round(eff, 4)}
+           for n, v, pr, w, eff in rows], open(os.path.join(out, "rows_%s.json" % name), "w"))
 PY
 done | tee "$OUT/table.txt"
 timeout 3000 python -m pytest tests/test_multigpu_gpu.py -m gpu -q --tb=short 2>&1 | tail -5 | tee "$OUT/multigpu_equality.txt"
+python - "$OUT" "$NGPU" <<'PY'
+import json, os, subprocess, sys, time
+out, ngpu = sys.argv[1], int(sys.argv[2])
+rec = {"skipped": False, "source": "tools/scale_sweep.sh (builder- or operator-run; the driver's own SCALE record supersedes it)",
+       "gpus_visible": ngpu, "measured_at_utc": time.strftime("%Y-%m-%d %H:%M", time.gmtime()), "scaling": "weak",
+       "commit": subprocess.run(["git", "rev-parse", "--short", "HEAD"], capture_output=True, text=True).stdout.strip() or None,
+       "target": "north_star: >= 2000 SR images/s on 8 x MI355X (8 x the single-GPU rate of BENCH is the projection; this file is the measurement)",
+       "configs": {}}
+for name, what in (("sr", "BASELINE configs[2]: batch 128 per GPU, uint8 all-gather of every step inside the timed region"),
+                   ("mixed", "BASELINE configs[4]: mixed widths, work-balanced shards")):
+    p = os.path.join(out, "rows_%s.json" % name)
+    rec["configs"][name] = {"workload": what, "rows": json.load(open(p)) if os.path.isfile(p) else []}
+eq = open(os.path.join(out, "multigpu_equality.txt")).read().strip().splitlines()
+rec["gathered_equals_single_gpu_test"] = eq[-1] if eq else "not run"
+if ngpu < 2:
+    rec["note"] = "fewer than 2 GPUs visible: only the N = 1 rows exist; the equality tests for 2 / 4 / 8 ranks were skipped"
+json.dump(rec, open(os.path.join(out, "SCALE_manual.json"), "w"), indent=1)
+print("[scale_sweep] wrote %s" % os.path.join(out, "SCALE_manual.json"))
+PY
