@@ -105,6 +105,7 @@ def parse():
     ap.add_argument("--cpu-images", type=int, default=4, help="images timed on the host CPU oracle (0 = skip); ~3.5 s each on 32 threads")
     ap.add_argument("--no-secondary", action="store_true", help="skip the secondary throughput measurements")
     ap.add_argument("--secondary-steps", type=int, default=3, help="timed steps of every secondary measurement (the headline uses --steps)")
+    ap.add_argument("--glyph-chunk", type=int, default=0, help="glyphs per TSPGAN call inside the batched driver (0: MarconetPipeline's default, 1024)")
     ap.add_argument("--no-regimes", action="store_true", help="skip the parity sample on the trained-like weight regime")
     ap.add_argument("--cpu-threads", type=int, default=32, help="cap on host threads for the CPU baseline")
     ap.add_argument("--no-gather", action="store_true")
@@ -265,7 +266,7 @@ def main():
     sde, sdg, sds, weights_source = checkpoints.load_state_dicts()
     enc, gan, sr = checkpoints.build_networks(sde, sdg, sds, dev)
     # the product's defaults (check_finite included: on for the half-range modes, one flag read back per batch)
-    pipe = MarconetPipeline(enc, gan, sr, precision=a.precision)
+    pipe = MarconetPipeline(enc, gan, sr, precision=a.precision, **({"glyph_chunk": a.glyph_chunk} if a.glyph_chunk > 0 else {}))
     pdt = PDT[a.precision]
 
     B, n = a.batch, a.glyphs

@@ -192,6 +192,11 @@ int mnet_upsample2x_nhwc(const void* src, void* dst, int32_t dtype, int32_t n, i
  * applied once per element here instead of once per filter tap inside the conv (networks.py:283-296) */
 int mnet_upsample2x_scale_nhwc(const void* src, void* dst, int32_t dtype, int32_t n, int32_t h, int32_t w,
                                int32_t c, const float* scale, void* stream);
+/* the same with the output in another storage type: dst_dtype == dtype, or MNET_F16 for an MNET_F16X2 / MNET_F16M input (the batched
+ * driver's image-only generator level, models/networks.py:161-164, reads the 64-px prior in the mode's storage and continues in plain
+ * f16 — no separate mnet_convert pass over that map) */
+int mnet_upsample2x_convert_nhwc(const void* src, int32_t dtype, void* dst, int32_t dst_dtype, int32_t n, int32_t h, int32_t w,
+                                 int32_t c, const float* scale, void* stream);
 
 /* K11 apply: y = f(x * scale[n,c] + shift[n,c]), f = swish if swish else identity (shift may be NULL).
  * GroupNorm-normalise + swish once per element (networks.py:508-509,511-512) — the conv prologue form of the same

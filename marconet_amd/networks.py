@@ -24,6 +24,7 @@ from .textvit_arch import TextViT as TextEncoder
 
 _STYLE_NORM = not bool(int(os.environ.get("MNET_NO_STYLE_NORM", "0")))     # A/B knob (tests): style rows normalised by a power of two
 _FOLD_SKIP = not bool(int(os.environ.get("MNET_NO_FOLD_SKIP", "0")))       # A/B knob: ResTextBlockV2's 1x1 skip conv as extra K of its conv2
+_FUSE_IMG_CONVERT = os.environ.get("MNET_NO_FUSE_IMG_CONVERT", "0") != "1"   # image-only levels: the f16 conversion rides in the up-sample's store (A/B knob)
 _FUSE_CONV1_MOD = os.environ.get("MNET_NO_FUSE_CONV1_MOD", "0") != "1"      # conv1's style multiply in the SelectText gather (A/B knob)
 RGB_PAD = 8      # 3-channel tensors are carried with 8 channels (one 16-byte fp16 chunk); 32 in the split-half mode (rgb_pad)
 
@@ -279,14 +280,17 @@ class TextGenerator(nn.Module):
         for lvl in range(len(pk["rgbs"])):
             if not need_image and p64 is not None and p32 is not None:
                 return None, p64, p32
-            pkl = pk
+            pkl, up_dtype = pk, None
             if pk_img is not pk and p64 is not None and p32 is not None:      # image-only levels (see ``image_precision``)
                 pkl = pk_img
-                x = ops.convert(x, torch_dtype(image_precision))
+                up_dtype = torch_dtype(image_precision)
+                if not (_FUSE_IMG_CONVERT and up_dtype == torch.float16 and is_split(x.dtype)):
+                    x = ops.convert(x, up_dtype)                              # (the general case: its own pass)
+                # else: the up-sample below reads the prior level in the mode's storage and writes plain f16 (round 5: no convert pass)
             La, Lb = pkl["convs"][2 * lvl], pkl["convs"][2 * lvl + 1]
             sa, da = self._style(La)
             sb, db = self._style(Lb)
-            xu = ops.upsample2x(x, scale=sa)                                   # bilinear ×2 (:293) with ·s_a fused
+            xu = ops.upsample2x(x, scale=sa, out_dtype=up_dtype if up_dtype != x.dtype else None)   # bilinear ×2 (:293) with ·s_a fused
             xa = self._styled(La, xu, sa, da, premodulated=True, post=sb)      # emits x_a·s_b (x_a has no other reader)
             del xu
             wx = xa.shape[2]                                                   # this level's width (absolute, see below)

@@ -246,14 +246,15 @@ def nhwc_to_nchw(src, c=None):
 
 
 @_plumbing
-def upsample2x(src, scale=None):
-    """bilinear x2 (align_corners=False); optional per-(n,c) fp32 multiplier fused into the store"""
+def upsample2x(src, scale=None, out_dtype=None):
+    """bilinear x2 (align_corners=False); optional per-(n,c) fp32 multiplier fused into the store; ``out_dtype``: torch.float16 for a
+    split-half / fp16+8 source (the conversion rides in the store: no separate convert pass), default the source's storage type"""
     lib = _lib.load()
     _need_cuda(src, scale)
     n, h, w, c = src.shape
-    dst = new_tensor((n, 2 * h, 2 * w, c), src.dtype, src.device)
-    stats.tail("upsample2x", (src, dst), lambda: _lib.check(lib.mnet_upsample2x_scale_nhwc(_p(src), _p(dst), _dt(src), n, h, w, c, _p(scale), _stream()),
-                                                            "mnet_upsample2x_scale_nhwc"))
+    dst = new_tensor((n, 2 * h, 2 * w, c), out_dtype or src.dtype, src.device)
+    stats.tail("upsample2x", (src, dst), lambda: _lib.check(lib.mnet_upsample2x_convert_nhwc(_p(src), _dt(src), _p(dst), _dt(dst), n, h, w, c, _p(scale), _stream()),
+                                                            "mnet_upsample2x_convert_nhwc"))
     return dst
 
 

@@ -217,6 +217,22 @@ def test_upsample2x(dtype):
     _check("upsample2x %s" % dtype, _nchw(y), ref, dtype)
 
 
+@pytest.mark.parametrize("dtype", [SPLIT, MX])
+def test_upsample2x_into_f16(dtype):
+    """round 5: a split-half / fp16+8 source up-sampled straight into plain f16 (the image-only generator level of the batched driver:
+    no separate convert pass) — the interpolation of the source's values, times the fused per-(n, c) scale, rounded to f16 once"""
+    ops = _ops()
+    x = _q(_rnd((2, 64, 6, 9), 121), dtype)
+    sc = _rnd((2, 64), 122).abs() + 0.5
+    ref = F.interpolate(x, scale_factor=2, mode="bilinear", align_corners=False) * sc[:, :, None, None]
+    y = ops.upsample2x(_nhwc(x, dtype), scale=sc.to(DEV), out_dtype=torch.float16)
+    torch.cuda.synchronize()
+    assert y.dtype == torch.float16 and tuple(y.shape) == (2, 12, 18, 64)
+    _check("upsample2x %s -> f16" % dtype, _nchw(y), ref, torch.float16)
+    with pytest.raises(Exception):
+        ops.upsample2x(_nhwc(x, torch.float16), out_dtype=_dt(MX))           # only towards f16
+
+
 @pytest.mark.parametrize("dtype", ALL_DTYPES)
 @pytest.mark.parametrize("c", [64, 256, 512])
 def test_groupnorm_affine(c, dtype):
@@ -741,11 +757,12 @@ def test_style_rows_and_scaled_demod():
 
 
 @pytest.mark.parametrize("dtype", ALL_DTYPES)
-@pytest.mark.parametrize("c", [128, 512])
-def test_torgb_kernel(c, dtype):
-    """ToRGB.forward (models/networks.py:313-321): modulated 1x1 conv (no demodulation) + bias + bilinear x2 of the skip + tanh"""
+@pytest.mark.parametrize("c,hw", [(128, (6, 10)), (512, (6, 10)), (256, (64, 64)), (128, (36, 50))])
+def test_torgb_kernel(c, hw, dtype):
+    """ToRGB.forward (models/networks.py:313-321): modulated 1x1 conv (no demodulation) + bias + bilinear x2 of the skip + tanh
+    (the larger maps: several trips per workgroup, a ragged last trip)"""
     ops = _ops()
-    n, h, w = 3, 6, 10
+    n, (h, w) = 3, hw
     x = _q(_rnd((n, c, h, w), 90), dtype)
     wt = _rnd((3, c), 91, 1.0 / math.sqrt(c))
     style = _rnd((n, c), 92).abs() + 0.5
