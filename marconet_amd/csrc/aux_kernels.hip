@@ -379,156 +379,6 @@ __global__ void __launch_bounds__(256) adain_crop_kernel(const T* __restrict__ p
     }
 }
 
-// ---------------------------------------------------------------------------- the same kernel with more bytes in flight (round 5)
-// adain_crop_kernel above keeps ONE prior and ONE feature chunk in flight per thread and needs 64 KiB of LDS for its fp64 fold (two workgroups
-// = 8 waves per CU): 32 KiB in flight per CU — a chain of exposed HBM latencies (3.7 TB/s of algorithmic bytes, profiles/r4z_*).  Here: four
-// pixels per trip in the statistics pass (8 loads issued before the first use) and two in the write pass, and the fold goes through the LDS one
-// statistic at a time (16 KiB) — 28 KiB per workgroup, so the register file, not the LDS, sets the occupancy.  Per thread the pixels are
-// accumulated in the same order and the lanes of a channel are folded in the same order: BIT-IDENTICAL results (tests/test_kernels_gpu.py).
-template <typename T>
-__global__ void __launch_bounds__(256) adain_crop4_kernel(const T* __restrict__ prior, const T* __restrict__ feat,
-                                                          T* __restrict__ out, int S, int C, int FW,
-                                                          const int* __restrict__ g_img, const int* __restrict__ g_x1,
-                                                          const int* __restrict__ g_y1, const int* __restrict__ g_w,
-                                                          const float* __restrict__ gn_gamma, const float* __restrict__ gn_beta,
-                                                          float gn_eps, float* __restrict__ gn_scale, float* __restrict__ gn_shift) {
-    constexpr int N = Vec<T>::N;
-    constexpr int U1 = 4, U2 = 2;
-    extern __shared__ __attribute__((aligned(16))) unsigned char dyn[];
-    const int g = blockIdx.x, t = threadIdx.x;
-    const int cpp = C / N, plane = 256 / cpp;
-    const int ch = t % cpp, pl = t / cpp;
-    const int img = g_img[g], x1 = g_x1[g], y1 = g_y1[g], gw = g_w[g];
-    double* red = reinterpret_cast<double*>(dyn);                       // [256][N]: one statistic at a time
-    float* stat = reinterpret_cast<float*>(dyn + (size_t)256 * N * sizeof(double));       // [4][C]: pm, ps, fm, fs
-    double* gsum = reinterpret_cast<double*>(stat + 4 * C);              // [2][2C]: per output channel sum, sum of squares
-    float* gmr = reinterpret_cast<float*>(gsum + 4 * C);                 // [2C/32][2]: group mean, rstd
-    const T* pbase = prior + (size_t)g * S * S * C + (size_t)ch * N;
-    const T* fbase = feat + (size_t)img * S * FW * C + (size_t)ch * N;
-    const int npx = S * gw;
-    double acc[4][N];                                                   // prior sum, prior sum of squares, feature sum, feature sum of squares
-#pragma unroll
-    for (int k = 0; k < 4; ++k)
-#pragma unroll
-        for (int j = 0; j < N; ++j) acc[k][j] = 0.0;
-    for (int p0 = pl; p0 < npx; p0 += U1 * plane) {
-        Raw<T> ra[U1], rb[U1];
-#pragma unroll
-        for (int u = 0; u < U1; ++u) {                                  // (a pixel beyond the window re-reads the trip's first one: whole quads, in range)
-            const int p = p0 + u * plane < npx ? p0 + u * plane : p0;
-            const int y = p / gw, x = p - y * gw;
-            ra[u] = ldraw<T>(pbase + ((size_t)y * S + (y1 + x)) * C);
-            rb[u] = ldraw<T>(fbase + ((size_t)y * FW + (x1 + x)) * C);
-        }
-#pragma unroll
-        for (int u = 0; u < U1; ++u) {
-            if (p0 + u * plane >= npx) break;
-            float a[N], b[N];
-            unpackr<T>(ra[u], a);
-            unpackr<T>(rb[u], b);
-#pragma unroll
-            for (int j = 0; j < N; ++j) {
-                acc[0][j] += (double)a[j]; acc[1][j] += (double)a[j] * (double)a[j];
-                acc[2][j] += (double)b[j]; acc[3][j] += (double)b[j] * (double)b[j];
-            }
-        }
-    }
-    // thread c (< C; C <= 512: at most two channels per thread) folds the pixel lanes of channel c, one statistic per round
-    double tot[2][4];
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        if (k) __syncthreads();
-#pragma unroll
-        for (int j = 0; j < N; ++j) red[(size_t)t * N + j] = acc[k][j];
-        __syncthreads();
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int c = t + 256 * i;
-            double s_ = 0;
-            if (c < C) {
-                const int chn = c / N, j = c % N;
-                for (int q = 0; q < plane; ++q) s_ += red[(size_t)(q * cpp + chn) * N + j];
-            }
-            tot[i][k] = s_;
-        }
-    }
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const int c = t + 256 * i;
-        if (c >= C) continue;
-        const double a0 = tot[i][0], a1 = tot[i][1], b0 = tot[i][2], b1 = tot[i][3];
-        const double cnt = (double)npx;
-        const double pm = a0 / cnt, fm = b0 / cnt;
-        // unbiased variance (torch .var default, networks.py:522) + eps 1e-5, then sqrt
-        double pv = (a1 - cnt * pm * pm) / (cnt - 1.0), fv = (b1 - cnt * fm * fm) / (cnt - 1.0);
-        if (pv < 0) pv = 0; if (fv < 0) fv = 0;
-        stat[c] = (float)pm; stat[C + c] = sqrtf((float)pv + 1e-5f);
-        stat[2 * C + c] = (float)fm; stat[3 * C + c] = sqrtf((float)fv + 1e-5f);
-        if (gn_scale) {     // (closed-form sums of the concatenated output: see adain_crop_kernel)
-            const double r = (double)stat[3 * C + c] / (double)stat[C + c];
-            double dev = a1 - cnt * pm * pm;
-            if (dev < 0) dev = 0;
-            gsum[c] = cnt * fm;            gsum[2 * C + c] = r * r * dev + cnt * fm * fm;
-            gsum[C + c] = b0;              gsum[3 * C + c] = b1;
-        }
-    }
-    __syncthreads();
-    if (gn_scale) {
-        const int G2 = 2 * C / 32;
-        for (int gq = t; gq < G2; gq += 256) {
-            double s1 = 0.0, s2 = 0.0;
-            for (int k = 0; k < 32; ++k) { s1 += gsum[gq * 32 + k]; s2 += gsum[2 * C + gq * 32 + k]; }
-            const double cnt = (double)npx * 32.0;
-            const double mean = s1 / cnt;
-            double var = s2 / cnt - mean * mean;
-            if (var < 0.0) var = 0.0;
-            gmr[2 * gq] = (float)mean; gmr[2 * gq + 1] = (float)(1.0 / sqrt(var + (double)gn_eps));
-        }
-        __syncthreads();
-        for (int c = t; c < 2 * C; c += 256) {
-            const float ga = gn_gamma[c] * gmr[2 * (c / 32) + 1];
-            gn_scale[(size_t)g * 2 * C + c] = ga;
-            gn_shift[(size_t)g * 2 * C + c] = gn_beta[c] - gmr[2 * (c / 32)] * ga;
-        }
-    }
-    T* obase = out + (size_t)g * S * S * 2 * C;
-    const int c0 = ch * N;
-    float pm_[N], ps_[N], fm_[N], fs_[N];
-#pragma unroll
-    for (int j = 0; j < N; ++j) { pm_[j] = stat[c0 + j]; ps_[j] = stat[C + c0 + j]; fm_[j] = stat[2 * C + c0 + j]; fs_[j] = stat[3 * C + c0 + j]; }
-    const int SS = S * S;
-    for (int p0 = pl; p0 < SS; p0 += U2 * plane) {
-        Raw<T> ra[U2], rb[U2];
-        bool in[U2];
-#pragma unroll
-        for (int u = 0; u < U2; ++u) {
-            const int p = p0 + u * plane;
-            const int y = p / S, x = p - y * S;
-            in[u] = p < SS && x < gw;
-            ra[u] = zero_raw<T>(); rb[u] = zero_raw<T>();
-            if (in[u]) {
-                ra[u] = ldraw<T>(pbase + ((size_t)y * S + (y1 + x)) * C);
-                rb[u] = ldraw<T>(fbase + ((size_t)y * FW + (x1 + x)) * C);
-            }
-        }
-#pragma unroll
-        for (int u = 0; u < U2; ++u) {
-            const int p = p0 + u * plane;
-            if (p >= SS) break;
-            Raw<T> oa = zero_raw<T>();
-            if (in[u]) {
-                float a[N], o[N];
-                unpackr<T>(ra[u], a);
-#pragma unroll
-                for (int j = 0; j < N; ++j) o[j] = (a[j] - pm_[j]) / ps_[j] * fs_[j] + fm_[j];
-                oa = packr<T>(o);
-            }
-            straw<T>(obase + (size_t)p * 2 * C + c0, oa);
-            straw<T>(obase + (size_t)p * 2 * C + C + c0, rb[u]);
-        }
-    }
-}
-
 static int adain_launch(const void* prior, const void* feat, void* out, int32_t dtype, int32_t G, int32_t S, int32_t C,
                         int32_t feat_w, const int32_t* g_img, const int32_t* g_x1, const int32_t* g_y1, const int32_t* g_w,
                         const float* gamma, const float* beta, float eps, float* scale, float* shift, void* stream) {
@@ -540,20 +390,9 @@ static int adain_launch(const void* prior, const void* feat, void* out, int32_t 
                      "adain: C=%d unsupported or unaligned", C);
     MNET_CHECK_ALIGN(!is_split4(dtype) || (aligned128(prior) && aligned128(feat) && aligned128(out)), "adain: split-half tensors must be 128-byte aligned");
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-    // round 5: the form with four pixels per trip and a 16 KiB fold (adain_crop4_kernel: same bits); MNET_ADAIN_FORM=0 keeps the first form (A/B knob)
-    static const int form = [] { const char* e = getenv("MNET_ADAIN_FORM"); return e ? atoi(e) : 1; }();
-    if (form == 1 && C <= 512) {
-        const size_t lds4 = (size_t)256 * N * sizeof(double) + (size_t)4 * C * sizeof(float) + (size_t)4 * C * sizeof(double) + (size_t)(2 * C / 32) * 2 * sizeof(float);
-#define MNET_ADAIN4(TT) hipLaunchKernelGGL(adain_crop4_kernel<TT>, dim3(G), dim3(256), lds4, st, (const TT*)prior, (const TT*)feat, (TT*)out, S, C, feat_w, \
-                                           g_img, g_x1, g_y1, g_w, gamma, beta, eps, scale, shift)
-        if (dtype == MNET_F16X2) MNET_ADAIN4(hs);
-        else if (dtype == MNET_F16M) MNET_ADAIN4(hm);
-        else if (dtype == MNET_F16) MNET_ADAIN4(f16);
-        else MNET_ADAIN4(float);
-#undef MNET_ADAIN4
-        MNET_LAUNCH_CHECK("adain_crop4");
-        return MNET_OK;
-    }
+    // (round 5: a form of this kernel with four pixels in flight per thread and a 16 KiB fold — three workgroups per CU instead of two, bit-identical —
+    //  measured 24.2-24.9 ms per step against 23.2: the kernel is not latency-bound.  It reads the prior and the feature windows TWICE (statistics, then
+    //  apply): 102 GB of real traffic per step in 18.8 ms = 5.4 TB/s, the copy ceiling of this chip; `roofline.hbm_tail` books the algorithmic 69 GB.)
     const size_t lds = (size_t)256 * N * 4 * sizeof(double) + (size_t)4 * C * sizeof(float) + (size_t)4 * C * sizeof(double) +
                        (size_t)(2 * C / 32) * 2 * sizeof(float);
     static thread_local size_t lds_all[256][4] = {};                   // attribute raised once per (device, size) (not during graph capture replays)

@@ -228,17 +228,56 @@ __device__ __forceinline__ void hm_decode_lo(u32x2 lo8, float sl, float* o) {
         o[4 * d] = a[0] * sl; o[4 * d + 1] = a[1] * sl; o[4 * d + 2] = b[0] * sl; o[4 * d + 3] = b[1] * sl;
     }
 }
-template <> __device__ __forceinline__ void unpackr<hm>(const Raw<hm>& r, float* o) {
-    const f16x8 h = bitcast<f16x8>(r.hi);
-    float l[8];
-    hm_decode_lo(r.lo8, hm_lo_scale(r.e8), l);
-#pragma unroll
-    for (int j = 0; j < 8; ++j) o[j] = (float)h[j] + l[j];
+// Round 5 — the fp16+8 encode / decode on the mixed-precision VALU forms (MNET_HM_FAST, default on; -DMNET_HM_FAST=0 is the A/B build).
+// hipcc turns `(float)h + l * s` into v_cvt_f32_f16 + v_mul + v_add and `(v - (float)f16(v)) * inv` into v_cvt_f16_f32 + v_cvt_f32_f16 + v_sub +
+// v_mul NEXT TO the packed v_cvt_pk_f16_f32 it also emits for the stored halves (ISA of the 256x256 tile's epilogue): 5 VALU
+// instructions per encoded value, 3.5 per decoded one — and every streaming kernel of the fp16+8 mode decodes and encodes every element.
+//   v_fma_mix_f32 d, a, b, c   reads any of its operands as the low / high HALF of a register in place: decode = 1 instruction per value
+//                              (l * s + h), the lo residual v - h = h * (-1) + v = 1 instruction (exact, like the subtraction it replaces);
+//   v_cvt_scalef32_pk_fp8_f32  divides by a power of two (the exponent field of its scale operand) while it converts: the `* inv` disappears.
+// Same values, same roundings: l * s and v - h are exact, so the fused forms round exactly once where the separate ones did.
+#ifndef MNET_HM_FAST
+#define MNET_HM_FAST 1
+#endif
+// a * b + half(packed, HI)
+template <int HI> __device__ __forceinline__ float fma_mix_c16(float a, float b, unsigned packed) {
+    float d;
+    if constexpr (HI) asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "=v"(d) : "v"(a), "v"(b), "v"(packed));
+    else asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel_hi:[0,0,1]" : "=v"(d) : "v"(a), "v"(b), "v"(packed));
+    return d;
 }
+// c - half(packed, HI)   (= half * -1.0 + c)
+template <int HI> __device__ __forceinline__ float sub_mix_a16(float c, unsigned packed) {
+    float d;
+    if constexpr (HI) asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(d) : "v"(packed), "v"(c));
+    else asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(d) : "v"(packed), "v"(c));
+    return d;
+}
+// o[j] (+)= (float)hi[j] + lo8[j] * sl for the 8 channels of a chunk (hi: 8 packed halves, lo8: 8 e4m3 bytes)
+template <bool ACC = false>
+__device__ __forceinline__ void hm_decode8(u32x4 hi, u32x2 lo8, float sl, float* o) {
+#if MNET_HM_FAST
+#pragma unroll
+    for (int d = 0; d < 2; ++d) {
+        const f32x2 a = __builtin_amdgcn_cvt_pk_f32_fp8((int)lo8[d], false), b = __builtin_amdgcn_cvt_pk_f32_fp8((int)lo8[d], true);
+        const float t0 = fma_mix_c16<0>(a[0], sl, hi[2 * d]), t1 = fma_mix_c16<1>(a[1], sl, hi[2 * d]);
+        const float t2 = fma_mix_c16<0>(b[0], sl, hi[2 * d + 1]), t3 = fma_mix_c16<1>(b[1], sl, hi[2 * d + 1]);
+        if constexpr (ACC) { o[4 * d] += t0; o[4 * d + 1] += t1; o[4 * d + 2] += t2; o[4 * d + 3] += t3; }
+        else { o[4 * d] = t0; o[4 * d + 1] = t1; o[4 * d + 2] = t2; o[4 * d + 3] = t3; }
+    }
+#else
+    const f16x8 h = bitcast<f16x8>(hi);
+    float l[8];
+    hm_decode_lo(lo8, sl, l);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { if constexpr (ACC) o[j] += (float)h[j] + l[j]; else o[j] = (float)h[j] + l[j]; }
+#endif
+}
+template <> __device__ __forceinline__ void unpackr<hm>(const Raw<hm>& r, float* o) { hm_decode8(r.hi, r.lo8, hm_lo_scale(r.e8), o); }
 // E8M0 byte of the block scale from the block's max |hi| (as a float): 2^(floor(log2 m) - 7)
 __device__ __forceinline__ int hm_e8_of(float m) { return max(0, (int)((__builtin_bit_cast(unsigned, m) >> 23) & 255u) - 7); }
 // 8 lo bytes: e4m3((v - hi) * 2^11 / s), s = 2^(e8 - 127)
-__device__ __forceinline__ u32x2 hm_encode_lo(const float* o, const f16x8& h, int e8) {
+__device__ __forceinline__ u32x2 hm_encode_lo_ref(const float* o, const f16x8& h, int e8) {
     const float inv = e8 >= 11 ? __builtin_bit_cast(float, (unsigned)(265 - e8) << 23) : 0.f;      // 2^(11 + 127 - e8)
     u32x2 r;
 #pragma unroll
@@ -249,6 +288,26 @@ __device__ __forceinline__ u32x2 hm_encode_lo(const float* o, const f16x8& h, in
         r[d] = (unsigned)w;
     }
     return r;
+}
+__device__ __forceinline__ u32x2 hm_encode_lo(const float* o, const f16x8& h, int e8) {
+#if MNET_HM_FAST
+    // (v - hi) / 2^(e8 - 138): the conversion divides by the power of two whose exponent field its scale operand carries — field e8 - 11.  hi is a
+    // HALF: a block's largest |hi| is 0 or >= 2^-24, so e8 is 0 (an all-zero block) or >= 96 — the fields 1 ... 10, and the field 0 that e8 = 11
+    // would ask for, never occur; the all-zero block divides by 2^127: zero bytes (the reference form multiplies by 0 there)
+    const float sc = __builtin_bit_cast(float, (unsigned)(e8 >= 12 ? e8 - 11 : 254) << 23);
+    const u32x4 hp = bitcast<u32x4>(h);
+    u32x2 r;
+#pragma unroll
+    for (int d = 0; d < 2; ++d) {
+        s16x2 w = {0, 0};
+        w = __builtin_amdgcn_cvt_scalef32_pk_fp8_f32(w, sub_mix_a16<0>(o[4 * d], hp[2 * d]), sub_mix_a16<1>(o[4 * d + 1], hp[2 * d]), sc, false);
+        w = __builtin_amdgcn_cvt_scalef32_pk_fp8_f32(w, sub_mix_a16<0>(o[4 * d + 2], hp[2 * d + 1]), sub_mix_a16<1>(o[4 * d + 3], hp[2 * d + 1]), sc, true);
+        r[d] = bitcast<unsigned>(w);
+    }
+    return r;
+#else
+    return hm_encode_lo_ref(o, h, e8);
+#endif
 }
 __device__ __forceinline__ float quad_max(float m) {      // max over the 4 lanes of a quad (DPP quad_perm: xor 1, xor 2)
     m = fmaxf(m, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, m), 0xB1, 0xf, 0xf, true)));

@@ -152,7 +152,7 @@ __device__ __forceinline__ void dma_epilogue_mx(const ConvArgs& p, const f32x16 
             if (!xpose) {
                 unsigned char* yb = reinterpret_cast<unsigned char*>(p.y) + (size_t)pix * p.cout * 4 + (co >> 5) * 128;
 #pragma unroll
-                for (int c = 0; c < 4; ++c) { stg16(yb + c * 16, bitcast<u32x4>(hh[c])); lo[c] = hm_encode_lo(v + c * 8, hh[c], e8); }
+                for (int c = 0; c < 4; ++c) { stg16(yb + c * 16, bitcast<u32x4>(hh[c])); lo[c] = hm_encode_lo_ref(v + c * 8, hh[c], e8); }
                 // lo bytes in the order 0-7,16-23 | 8-15,24-31 (slot of chunk c = hm_lo_slot(c))
                 stg16(yb + 64, u32x4{lo[0][0], lo[0][1], lo[2][0], lo[2][1]});
                 stg16(yb + 80, u32x4{lo[1][0], lo[1][1], lo[3][0], lo[3][1]});
@@ -160,12 +160,15 @@ __device__ __forceinline__ void dma_epilogue_mx(const ConvArgs& p, const f32x16 
                 stg16(yb + 112, u32x4{0u, 0u, 0u, 0u});
                 continue;
             }
+            // (hm_encode_lo_ref / act_apply_vec, not the mixed-precision VALU forms of common.h: with them this epilogue executes ~25 % fewer VALU
+            //  instructions and the tile runs 0 ... -1 % — same-box A/B, profiles/r5c_hm_fast_ab.txt: the epilogue waits for its parameter loads and its
+            //  stores, not for the VALU.  The streaming kernels keep the fast forms: +1 ... +2.5 % there.)
             // ---- through the LDS: two rounds of 4 pieces per lane (the hi halves, then lo bytes | lo bytes | scale | padding)
             unsigned L = (unsigned)lane;
             asm volatile("" : "+v"(L));                                     // the scratch addresses are re-derived here: hoisted out of the tile loop they would
             const unsigned wsw = (L >> 1) & 3u, j = L & 3u;                 // live through the k-loop, which has no register to spare (256 allocated)
 #pragma unroll
-            for (int c = 0; c < 4; ++c) lo[c] = hm_encode_lo(v + c * 8, hh[c], e8);
+            for (int c = 0; c < 4; ++c) lo[c] = hm_encode_lo_ref(v + c * 8, hh[c], e8);
 #pragma unroll 1
             for (int half = 0; half < 2; ++half) {
                 u32x4 pc[4];

@@ -16,7 +16,7 @@ sys.path.insert(0, ROOT)
 
 VARIANTS = [
     ("default (round 5 forms)", {}),
-    ("round-4 forms: MNET_ADAIN_FORM=0 MNET_TORGB_TRIPS=1", {"MNET_ADAIN_FORM": "0", "MNET_TORGB_TRIPS": "1"}),
+    ("round-4 forms: MNET_TORGB_TRIPS=1", {"MNET_TORGB_TRIPS": "1"}),
 ]
 
 
