@@ -106,6 +106,13 @@ typedef struct {
     const float* post_scale;    /* [n][cout] or NULL: multiplied AFTER act — lets a StyledConv emit its
                                  * output already modulated by the NEXT layer's style (networks.py:283-284) */
     void* y;                    /* NHWC [n,ho,wo,cout]                                            */
+    float* gn_partial;          /* NULL, or (ABI v4) GroupNorm partial sums of the OUTPUT, written by the epilogue that holds the values anyway:
+                                 * [n*ho*wo / 32][cout / 32][2] fp32 = (sum, sum of squares) over 32 consecutive output pixels x the 32 channels of a
+                                 * group (networks.py:487-493: GroupNorm(C/32 groups)), of the values as they leave the epilogue (after bias /
+                                 * activation / post_scale, before the storage rounding); pixels at columns >= valid_w[n] are left out.  Fixed
+                                 * reduction tree, independent of the tile configuration: the same bits for every launch size.  Removes the separate
+                                 * statistics pass over the map (mnet_groupnorm_affine_from_partial folds them).  Needs an MNET_F16M launch the LDS-DMA /
+                                 * strip kernels take, stride 1, cout % 32 == 0 and ho*wo % 32 == 0 — MNET_E_ARG otherwise (nothing is enqueued). */
 } mnet_conv_desc;
 
 int mnet_conv2d_nhwc(const mnet_conv_desc* d, void* stream);
@@ -214,6 +221,10 @@ int mnet_affine_act_nhwc(const void* x, void* y, int32_t dtype, int32_t n, int32
 int mnet_groupnorm_affine(const void* x, int32_t dtype, int32_t n, int32_t h, int32_t w, int32_t c,
                           const int32_t* valid_w, const float* gamma, const float* beta, float eps,
                           double* partial, int32_t slices, float* scale, float* shift, void* stream);
+/* the same affine from the partial sums a convolution's epilogue wrote (mnet_conv_desc.gn_partial: [n*h*w/32][c/32][2] fp32): fp64 fold in a fixed
+ * order, count = h * min(valid_w[n], w) * 32 per group.  One wave per (image, group): no pass over the map. */
+int mnet_groupnorm_affine_from_partial(const float* partial, int32_t n, int32_t h, int32_t w, int32_t c, const int32_t* valid_w,
+                                       const float* gamma, const float* beta, float eps, float* scale, float* shift, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * per-glyph prior transform of TSPSRNet (networks.py:421-449 and :455-482)

@@ -36,6 +36,7 @@ class ConvDesc(ctypes.Structure):
         ("act", c_int),
         ("post_scale", c_void_p),
         ("y", c_void_p),
+        ("gn_partial", c_void_p),
     ]
 
 
@@ -56,6 +57,7 @@ SYMBOLS = {
     "mnet_affine_act_nhwc": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_void_p]),
     "mnet_groupnorm_affine": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p,
                                       c_float, c_void_p, c_int, c_void_p, c_void_p, c_void_p]),
+    "mnet_groupnorm_affine_from_partial": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_void_p, c_void_p]),
     "mnet_adain_crop_concat": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int,
                                        c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "mnet_adain_crop_concat_gn": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int,

@@ -271,6 +271,43 @@ extern "C" int mnet_groupnorm_affine(const void* x, int32_t dtype, int32_t n, in
     return MNET_OK;
 }
 
+// ---------------------------------------------------------------------------- the same affine from epilogue partial sums (round 5)
+// partial[(n * frags + f) * G + g] = (sum, sum of squares) of fragment f (32 consecutive pixels) x group g, written by the producing convolution's
+// epilogue (mnet_conv_desc.gn_partial).  One wave per (group, image): lane l folds fragments l, l + 64, ... in fp64, then a fixed butterfly.
+__global__ void __launch_bounds__(64) gn_finalize_frag_kernel(const float* __restrict__ partial, int frags, int H, int W, int C,
+                                                              const int* __restrict__ valid_w, const float* __restrict__ gamma,
+                                                              const float* __restrict__ beta, float eps, float* __restrict__ scale,
+                                                              float* __restrict__ shift) {
+    const int g = blockIdx.x, n = blockIdx.y, lane = threadIdx.x, G = C / 32;
+    const f32x2* pp = reinterpret_cast<const f32x2*>(partial) + (size_t)n * frags * G + g;
+    double S = 0.0, SS = 0.0;
+    for (int f = lane; f < frags; f += 64) { const f32x2 v = pp[(size_t)f * G]; S += (double)v[0]; SS += (double)v[1]; }
+    S = wave_sum_d(S); SS = wave_sum_d(SS);
+    const int vw = valid_w ? min(valid_w[n], W) : W;
+    const double cnt = (double)H * vw * 32.0;
+    const double mean = S / cnt;
+    double var = SS / cnt - mean * mean;
+    if (var < 0.0) var = 0.0;
+    const float rstd = (float)(1.0 / sqrt(var + (double)eps));
+    if (lane < 32) {
+        const int c = g * 32 + lane;
+        const float ga = gamma[c] * rstd;
+        scale[(size_t)n * C + c] = ga;
+        shift[(size_t)n * C + c] = beta[c] - (float)mean * ga;
+    }
+}
+
+extern "C" int mnet_groupnorm_affine_from_partial(const float* partial, int32_t n, int32_t h, int32_t w, int32_t c, const int32_t* valid_w,
+                                                  const float* gamma, const float* beta, float eps, float* scale, float* shift, void* stream) {
+    MNET_CHECK_ARG(partial && gamma && beta && scale && shift, "groupnorm_from_partial: null pointer");
+    MNET_CHECK_ARG(n > 0 && n <= 65535 && h > 0 && w > 0 && c > 0 && c % 32 == 0 && (h * w) % 32 == 0, "groupnorm_from_partial: bad geometry (c %% 32, h*w %% 32)");
+    MNET_CHECK_ALIGN((reinterpret_cast<uintptr_t>(partial) & 7u) == 0, "groupnorm_from_partial: partial must be 8-byte aligned");
+    hipLaunchKernelGGL(gn_finalize_frag_kernel, dim3(c / 32, n), dim3(64), 0, reinterpret_cast<hipStream_t>(stream), partial, h * w / 32, h, w, c,
+                       valid_w, gamma, beta, eps, scale, shift);
+    MNET_LAUNCH_CHECK("gn_finalize_frag");
+    return MNET_OK;
+}
+
 // ============================================================================ AdaIN + crop + concat (per glyph)
 // one workgroup per glyph. pass 1: fp64 sums of the prior crop and the feature crop per channel;
 // pass 2: write [S,S,2C] (zeros beyond the glyph's width).

@@ -19,6 +19,9 @@ struct ConvArgs {
     int x1_center;           // MNET_CONV_ALGO_FLAG_X1_CENTER: the second source is walked at the centre tap only (LDS-DMA kernels: ktiles = taps * c0 / 64 + c1 / 64,
     int center_tap, center_tpx;   //   physical channels); its tap index kh/2 * kw + kw/2 and input-pixel offset kh/2 * w + kw/2 relative to tap 0
     int howo_shift, wo_shift;     // log2 of ho * wo / of wo when they are powers of two, else -1 (LDS-DMA kernels: the per-tile set-up divides by them, set by the launcher)
+    // (LAST, and read from the kernel-argument segment at its point of use: the 256-VGPR tiles' register allocation is sensitive to the layout of this block —
+    //  the same field placed before howo_shift put a scratch reload into the software-pipelined tile's slab loop, tools/isa_hot_scratch.py)
+    float* gn_partial;       // mnet_conv_desc.gn_partial: per (32-pixel fragment, 32-channel group) sum / sum of squares of the output, written by dma_epilogue_mx
 };
 
 // conv_igemm_dma.hip

@@ -1,6 +1,7 @@
 // Pieces shared by the two LDS-DMA convolution kernels (conv_igemm_dma.hip: one k-slab of activations per filter tap;
 // conv_strip_dma.hip: one activation strip per filter row, reused by its three taps).
 #pragma once
+#include <cstddef>
 #include <cstdlib>
 #include "common.h"
 #include "conv_args.h"
@@ -74,7 +75,21 @@ constexpr int dma_mx_xpose_bytes(int lds) { return !(MNET_MX_XPOSE && MX) ? 0 : 
 // ds_write_b128 and the 16-lane groups of ds_read_b128 (MI355X_MICROARCH.md, LDS).  One wave's LDS operations execute in order: no waits.
 // XL: lanes whose blocks fit the scratch at once — 64 (4 KiB per wave) or 16 (1 KiB per wave: the 64-lane round becomes four 16-lane rounds, one
 // read and one store per lane each).
-template <int BC, int BP, int WC, int WP, int FC, int FP, int XL = 64>
+// ConvArgs::gn_partial read from the kernel-argument segment (ConvArgs is the LDS-DMA / strip kernels' only argument, at offset 0)
+__device__ __forceinline__ float* kernarg_gn_partial() {
+#if defined(__HIP_DEVICE_COMPILE__)
+    typedef __attribute__((address_space(4))) const char* karg_t;
+    karg_t k = (karg_t)__builtin_amdgcn_kernarg_segment_ptr();
+    return *(float* const volatile __attribute__((address_space(4)))*)(k + offsetof(ConvArgs, gn_partial));
+#else
+    return nullptr;
+#endif
+}
+
+// GN: this instantiation can write the GroupNorm partial sums (ConvArgs::gn_partial).  The software-pipelined tiles are built without it: the extra
+// live values of that block moved hipcc's spill choice into their slab loop (two scratch accesses on the hot path, tools/isa_hot_scratch.py); launches
+// that ask for the sums take the lock-step form of the same tile (conv_dma_pick), which stays clean.
+template <int BC, int BP, int WC, int WP, int FC, int FP, int XL = 64, bool GN = true>
 __device__ __forceinline__ void dma_epilogue_mx(const ConvArgs& p, const f32x16 (&acc32)[FC / 2][FP / 2], int co0, int pix0, int wc, int wp, int lane,
                                                 unsigned char* xpose = nullptr) {
     static_assert(XL == 64 || XL == 16, "scratch of 4 KiB or 1 KiB per wave");
@@ -136,6 +151,29 @@ __device__ __forceinline__ void dma_epilogue_mx(const ConvArgs& p, const f32x16 
 #pragma unroll
                     for (int q = 0; q < 32; q += 4) { const f32x4 s4 = *reinterpret_cast<const f32x4*>(sp + q); v[q] *= s4[0]; v[q + 1] *= s4[1]; v[q + 2] *= s4[2]; v[q + 3] *= s4[3]; }
                 }
+            }
+            // (the pointer is read from the kernel-argument segment HERE — ConvArgs is the kernels' only argument, at offset 0 — instead of living in two
+            //  SGPRs across the slab loop: with 100 SGPRs allocated, one more live pair moved a spill slot and put two scratch reloads on the hot path)
+            float* gnp = nullptr;
+            if constexpr (GN) gnp = kernarg_gn_partial();
+            if (GN && gnp) {
+                // GroupNorm statistics of this output (round 5): the lane holds the 32 channels of ONE group for one pixel, the 32 lanes of a half hold 32
+                // consecutive pixels of one image (ho*wo % 32 == 0) — two fp32 sums per lane, a fixed xor tree over the half, one 8-byte store.  The tree and
+                // the fragment (32 pixels aligned to 32) are the same in every tile configuration: batch-invariant bits.  The consumer folds the fragments in
+                // fp64 (gn_finalize_frag_kernel): the separate statistics pass over the map (one read of it) is gone.
+                float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+                for (int q = 0; q < 32; ++q) { s1 += v[q]; s2 = fmaf(v[q], v[q], s2); }
+                bool ok = pix < p.npix && co < p.cout;
+                if (p.valid_w) {
+                    const int ow = p.wo_shift >= 0 ? (pix & (p.wo - 1)) : pix % p.wo;
+                    ok = ok && ow < p.valid_w[n_img];
+                }
+                s1 = ok ? s1 : 0.f; s2 = ok ? s2 : 0.f;
+#pragma unroll
+                for (int o = 1; o < 32; o <<= 1) { s1 += __shfl_xor(s1, o, 64); s2 += __shfl_xor(s2, o, 64); }
+                if ((lane & 31) == 0 && pixb < p.npix && co < p.cout)
+                    *reinterpret_cast<f32x2*>(gnp + ((size_t)(pixb >> 5) * (p.cout >> 5) + (co >> 5)) * 2) = f32x2{s1, s2};
             }
             if (!xpose && pix >= p.npix) continue;
             f16x8 hh[4];

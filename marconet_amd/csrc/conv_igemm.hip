@@ -558,6 +558,12 @@ static int conv_prepare(const mnet_conv_desc* d, int32_t algo, ConvArgs& a) {
     a.in_swish = d->in_swish; a.act = d->act; a.res_mod = d->res_mod;
     const int bk = d->dtype == MNET_F32 ? 32 : 64;
     a.ktiles = (a.K + bk - 1) / bk; a.tilesC = 0; a.ntiles = 0;
+    a.gn_partial = d->gn_partial;
+    if (a.gn_partial) {
+        MNET_CHECK_ARG(d->dtype == MNET_F16M && d->stride_h == 1 && d->stride_w == 1 && d->cout % 32 == 0 && (d->ho * d->wo) % 32 == 0 && d->ho == d->h && d->wo == d->w,
+                       "conv: gn_partial needs an MNET_F16M launch with stride 1, 'same' size, cout %% 32 == 0 and ho*wo %% 32 == 0");
+        MNET_CHECK_ALIGN((reinterpret_cast<uintptr_t>(d->gn_partial) & 7u) == 0, "conv: gn_partial must be 8-byte aligned");
+    }
     a.howo_shift = a.wo_shift = -1;      // "not a power of two" until an LDS-DMA launcher says otherwise (0 would read as a shift by 0)
     a.center_tap = (d->kh / 2) * d->kw + d->kw / 2;
     a.center_tpx = (d->kh / 2) * d->w + d->kw / 2;
@@ -613,18 +619,26 @@ static int conv_resolve(const mnet_conv_desc* d, int32_t algo, const ConvArgs& a
     return MNET_CONV_ALGO_REG_STAGED;
 }
 
+// conv_resolve + the one constraint that depends on its answer: only the fp16+8 LDS-DMA / strip epilogue (dma_epilogue_mx) writes gn_partial
+static int conv_resolve_checked(const mnet_conv_desc* d, int32_t algo, const ConvArgs& a) {
+    const int k = conv_resolve(d, algo, a);
+    if (k >= 0 && a.gn_partial && k < MNET_CONV_ALGO_DMA_CFG0)
+        return mnet_fail(MNET_E_ARG, "conv: gn_partial needs a launch the LDS-DMA / strip kernels take (this one resolves to kernel %d)", k);
+    return k;
+}
+
 extern "C" int mnet_conv2d_plan(const mnet_conv_desc* d, int32_t algo) {
     ConvArgs a;
     const int rc = conv_prepare(d, algo, a);
     if (rc != MNET_OK) return rc;
-    return conv_resolve(d, algo, a);
+    return conv_resolve_checked(d, algo, a);
 }
 
 extern "C" int mnet_conv2d_nhwc_ex(const mnet_conv_desc* d, int32_t algo, void* stream) {
     ConvArgs a;
     const int rc = conv_prepare(d, algo, a);
     if (rc != MNET_OK) return rc;
-    const int k = conv_resolve(d, algo, a);
+    const int k = conv_resolve_checked(d, algo, a);
     if (k < 0) return k;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     if (k >= MNET_CONV_ALGO_DMA_CFG16) return launch_conv_dma(a, st, k - MNET_CONV_ALGO_DMA_CFG16 + 16);
@@ -640,6 +654,7 @@ extern "C" int mnet_conv2d_splitk(const mnet_conv_desc* d, int32_t ksplit, float
     ConvArgs a;
     const int rc = conv_prepare(d, MNET_CONV_ALGO_AUTO, a);
     if (rc != MNET_OK) return rc;
+    MNET_CHECK_ARG(!a.gn_partial, "conv: gn_partial is not available on the split-K path");
     return launch_conv_skinny_splitk(a, d->dtype, ksplit, workspace, reinterpret_cast<hipStream_t>(stream));
 }
 

@@ -731,7 +731,7 @@ __global__ void __launch_bounds__(WC * WP * 64, WC * WP / 4) conv_dma_kernel(con
             if (c_kt == nk) {                                            // slab s-1 closed its tile: epilogue, then the next tile's scales and a clean accumulator
                 int co0, pix0;
                 tile_coords(c_v, co0, pix0);
-                dma_epilogue_mx<BC, BP, WC, WP, FC, FP, (XB == 1024 ? 16 : 64)>(p, acc32, co0, pix0, wc, wp, lane, xpose);
+                dma_epilogue_mx<BC, BP, WC, WP, FC, FP, (XB == 1024 ? 16 : 64), false>(p, acc32, co0, pix0, wc, wp, lane, xpose);
                 c_kt = 0; c_v += G;
                 if (p.tilesC > 1) load_scales(c_v);                      // (one channel tile: every tile has the same scales)
                 zero_acc();
@@ -748,7 +748,7 @@ __global__ void __launch_bounds__(WC * WP * 64, WC * WP / 4) conv_dma_kernel(con
         {
             int co0, pix0;
             tile_coords(c_v, co0, pix0);
-            dma_epilogue_mx<BC, BP, WC, WP, FC, FP, (XB == 1024 ? 16 : 64)>(p, acc32, co0, pix0, wc, wp, lane, xpose);
+            dma_epilogue_mx<BC, BP, WC, WP, FC, FP, (XB == 1024 ? 16 : 64), false>(p, acc32, co0, pix0, wc, wp, lane, xpose);
         }
         if constexpr (DBG == 6) {       // DIAGNOSTIC: phase sums of this wave over the first bytes of the output (32 bytes per wave)
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -1018,8 +1018,10 @@ int conv_dma_pick(const ConvArgs& a) {
         // placed by scheduling hints) on the four shapes that carry the step, +1.2 % end to end, same bytes (profiles/r4g_*)
         static const int env_mx_256 = [] { const char* e = getenv("MNET_MX_CFG256"); return e ? atoi(e) : 15; }();
         static const int env_mx_128 = [] { const char* e = getenv("MNET_MX_CFG128"); return e ? atoi(e) : 8; }();
-        if (a.cout >= 256) return big ? env_mx_256 : (t128 * ((a.cout + 255) / 256) < 200 ? 10 : 1);
-        if (a.cout >= 128) return big ? env_mx_128 : (t256 * ((a.cout + 127) / 128) < 200 ? 10 : 2);
+        // (launches that write GroupNorm partial sums take the lock-step forms 11 / 8 of the software-pipelined tiles 15 / 9: see launch_conv_dma)
+        const auto no_swp = [&](int id) { return a.gn_partial ? (id == 15 ? 11 : (id == 9 ? 8 : id)) : id; };
+        if (a.cout >= 256) return big ? no_swp(env_mx_256) : (t128 * ((a.cout + 255) / 256) < 200 ? 10 : 1);
+        if (a.cout >= 128) return big ? no_swp(env_mx_128) : (t256 * ((a.cout + 127) / 128) < 200 ? 10 : 2);
         static const int env_mx_64 = [] { const char* e = getenv("MNET_MX_CFG64"); return e ? atoi(e) : 13; }();       // id 13 = id 5 + hints: 260 vs 251
         return big ? env_mx_64 : 3;
     }
@@ -1036,7 +1038,11 @@ int conv_dma_pick(const ConvArgs& a) {
 }
 
 int launch_conv_dma(const ConvArgs& a, hipStream_t st, int cfg) {
-    return launch_dma_id(cfg >= 0 ? cfg : conv_dma_pick(a), a, st);
+    int id = cfg >= 0 ? cfg : conv_dma_pick(a);
+    // launches that write GroupNorm partial sums: the software-pipelined tiles are built without that block (dma_epilogue_mx<..., GN = false>) —
+    // their lock-step forms take over (id 15 -> 11, id 9 -> 8: the same tile shapes, the same MFMA sequence, the same bytes)
+    if (a.gn_partial && a.split == 2) id = id == 15 ? 11 : (id == 9 ? 8 : id);
+    return launch_dma_id(id, a, st);
 }
 
 // eligibility of the LDS-DMA path (see header comment); the caller falls back to the register-staged kernel

@@ -463,10 +463,28 @@ class TSPSRNet(nn.Module, _Precision):
 
     # ------------------------------------------------------------------ building blocks
     @staticmethod
-    def _c(pk, name, x, act=ops.ACT_NONE, x1=None, valid_w=None, in_scale=None, in_shift=None, residual=None):
+    def _c(pk, name, x, act=ops.ACT_NONE, x1=None, valid_w=None, in_scale=None, in_shift=None, residual=None, gn_partial=None):
         L = pk[name]
         return ops.conv2d(x, L["w"], L["cout"], 3, 3, L["stride"], (1, 1), x1=x1, bias=L["b"], act=act, valid_w=valid_w,
-                          in_scale=in_scale, in_shift=in_shift, in_swish=in_scale is not None, residual=residual)
+                          in_scale=in_scale, in_shift=in_shift, in_swish=in_scale is not None, residual=residual, gn_partial=gn_partial)
+
+    def _conv_gn(self, pk, name, x, norm, act=ops.ACT_NONE, x1=None, valid_w=None):
+        """conv ``name`` whose output feeds GroupNorm ``norm`` (networks.py:487-493) → (y, (scale, shift) of that GroupNorm).  Round 5: in the
+        fp16+8 mode the statistics are partial sums written by the conv's own epilogue (mnet_conv_desc.gn_partial, one wave-level fold per 32 pixels
+        x 32 channels) and folded by mnet_groupnorm_affine_from_partial — the separate statistics pass over the map is gone; every other storage
+        type / kernel keeps that pass (mnet_groupnorm_affine)."""
+        L = pk[name]
+        n, h, w, _ = x.shape
+        if ops.can_emit_gn_partial(x, x1, L["cout"], L["stride"], h, w):
+            part = ops.gn_partial_buffer(n, h, w, L["cout"], x.device)
+            try:
+                y = self._c(pk, name, x, act, x1=x1, valid_w=valid_w, gn_partial=part)
+                return y, ops.groupnorm_affine_from_partial(part, n, h, w, L["cout"], *pk[norm], 1e-6, valid_w)
+            except _lib.MarconetHipError as e:          # a launch the LDS-DMA / strip kernels do not take: MNET_E_ARG, nothing was enqueued
+                if "gn_partial" not in str(e):
+                    raise
+        y = self._c(pk, name, x, act, x1=x1, valid_w=valid_w)
+        return y, ops.groupnorm_affine(y, *pk[norm], 1e-6, valid_w)
 
     def _two(self, pk, name, x, x1=None, valid_w=None):
         """Sequential(SNconv, LeakyReLU(0.2), SNconv)."""
@@ -484,9 +502,8 @@ class TSPSRNet(nn.Module, _Precision):
         writes columns < valid_w only), and the AdaIN kernel writes zeros there anyway."""
         s1, h1 = norm1_affine if norm1_affine is not None else ops.groupnorm_affine(x, *pk[name + ".norm1"], 1e-6, valid_w)
         xs = ops.affine_act(x, s1, h1, swish=True)              # GN apply + swish once per element
-        h = self._c(pk, name + ".conv1", xs, valid_w=valid_w)
+        h, (s2, h2) = self._conv_gn(pk, name + ".conv1", xs, name + ".norm2", valid_w=valid_w)
         del xs
-        s2, h2 = ops.groupnorm_affine(h, *pk[name + ".norm2"], 1e-6, valid_w)
         ops.affine_act(h, s2, h2, swish=True, out=h)            # in place: h has no other reader
         skip = x
         if (name + ".conv2+out") in pk and _FOLD_SKIP:
@@ -578,9 +595,9 @@ class TSPSRNet(nn.Module, _Precision):
                 s32 = self._prior_transform(pk, "32", s32, p32, tab32)                           # :425-449
                 del p32
 
-            h = self._c(pk, "conv_up.1", ops.upsample2x(s32), ops.ACT_LRELU)                     # conv_up :359-365
+            h, aff = self._conv_gn(pk, "conv_up.1", ops.upsample2x(s32), "conv_up.3.norm1", ops.ACT_LRELU)   # conv_up :359-365
             del s32
-            h = self._res_block(pk, "conv_up.3", h)
+            h = self._res_block(pk, "conv_up.3", h, norm1_affine=aff)
             s64 = self._c(pk, "conv_up.4", h)
             del h
             if n64:
@@ -590,8 +607,8 @@ class TSPSRNet(nn.Module, _Precision):
 
             h = self._c(pk, "conv_final.0", s64, ops.ACT_LRELU)                                  # conv_final :367-376
             del s64
-            h = self._c(pk, "conv_final.3", ops.upsample2x(h), ops.ACT_LRELU)
-            h = self._res_block(pk, "conv_final.5", h)
+            h, aff = self._conv_gn(pk, "conv_final.3", ops.upsample2x(h), "conv_final.5.norm1", ops.ACT_LRELU)
+            h = self._res_block(pk, "conv_final.5", h, norm1_affine=aff)
             if h.shape[3] == 64:                      # conv_final.6 + tanh through the dedicated 3-output kernel
                 wr, br = pk["conv_final.6.rgb"]
                 y_nhwc, y_nchw = ops.conv3x3_rgb(h, wr, br, ops.ACT_TANH, nhwc=not nchw_out, nchw=nchw_out)

@@ -18,7 +18,7 @@ from .packing import MX_DTYPE, SPLIT_DTYPE, is_split, mx_weight_rows, new_tensor
 __all__ = ["conv2d", "linear", "nchw_to_nhwc", "nhwc_to_nchw", "upsample2x", "affine_act", "groupnorm_affine",
            "adain_crop_concat", "adain_crop_concat_gn", "glyph_scatter_affine", "layernorm", "token_mix", "attention", "pixelnorm",
            "embed_gather", "demod", "argmax_rows", "convert", "fused_bias_act", "sr_postprocess", "conv3x3_rgb", "torgb", "stats",
-           "pack_weights", "pack_wsq", "gather_rows", "style_rows", "nonfinite_flag",
+           "pack_weights", "pack_wsq", "gather_rows", "style_rows", "nonfinite_flag", "gn_partial_buffer", "can_emit_gn_partial", "groupnorm_affine_from_partial",
            "ACT_NONE", "ACT_RELU", "ACT_LRELU", "ACT_LRELU_SQRT2", "ACT_TANH", "ACT_GELU", "ACT_SIGMOID"]
 
 
@@ -136,10 +136,12 @@ stats = _Stats()
 @_plumbing
 def conv2d(x0, wgt, cout, kh=1, kw=1, stride=(1, 1), pad=(0, 0), x1=None, in_scale=None, in_shift=None,
            in_swish=False, valid_w=None, out_scale=None, bias=None, residual=None, res_mod=0, act=ACT_NONE,
-           post_scale=None, out=None, algo=0, splitk=0, x1_center=False):
+           post_scale=None, out=None, algo=0, splitk=0, x1_center=False, gn_partial=None):
     """mnet_conv2d_nhwc(_ex).  x0 [N,H,W,C0] (+ optional x1 [N,H,W,C1]); wgt packed [cout,kh,kw,C0+C1] same dtype.
     ``splitk`` > 0: mnet_conv2d_splitk with that many K-slices (fp32 filter == stride convs over <= 512 output pixels).
-    ``x1_center``: x1 enters through the filter's centre tap only (MNET_CONV_ALGO_FLAG_X1_CENTER: a 1x1 skip conv as extra K)."""
+    ``x1_center``: x1 enters through the filter's centre tap only (MNET_CONV_ALGO_FLAG_X1_CENTER: a 1x1 skip conv as extra K).
+    ``gn_partial``: fp32 [n*ho*wo/32, cout/32, 2] buffer (``gn_partial_buffer``) the epilogue fills with the GroupNorm partial sums of the output
+    (fp16+8 launches on the LDS-DMA / strip kernels only: MarconetHipError otherwise, nothing enqueued)."""
     lib = _lib.load()
     _need_cuda(x0, x1, wgt, in_scale, in_shift, valid_w, out_scale, bias, residual, post_scale, out)
     n, h, w, c0 = x0.shape
@@ -176,6 +178,12 @@ def conv2d(x0, wgt, cout, kh=1, kw=1, stride=(1, 1), pad=(0, 0), x1=None, in_sca
     d.act = act
     d.post_scale = None if post_scale is None else post_scale.data_ptr()
     d.y = out.data_ptr()
+    d.gn_partial = None
+    if gn_partial is not None:
+        _need_cuda(gn_partial)
+        if gn_partial.dtype != torch.float32 or gn_partial.numel() != (n * ho * wo // 32) * (cout // 32) * 2:
+            raise RuntimeError("conv2d: gn_partial must be fp32 [n*ho*wo/32, cout/32, 2]")
+        d.gn_partial = gn_partial.data_ptr()
     for t, nm in ((in_scale, "in_scale"), (in_shift, "in_shift"), (out_scale, "out_scale"), (bias, "bias"),
                   (post_scale, "post_scale")):
         if t is not None and t.dtype != torch.float32:
@@ -285,6 +293,29 @@ def groupnorm_affine(x, gamma, beta, eps=1e-6, valid_w=None):
     return scale, shift
 
 
+def gn_partial_buffer(n, h, w, c, device):
+    """buffer for conv2d(gn_partial=...): per (32-pixel fragment, 32-channel group) sum and sum of squares of the conv's output"""
+    return torch.empty((n * h * w // 32, c // 32, 2), dtype=torch.float32, device=device)
+
+
+def can_emit_gn_partial(x0, x1, cout, stride, ho, wo):
+    """the launches whose epilogue can write GroupNorm partial sums (mnet_conv_desc.gn_partial): fp16+8 storage on the LDS-DMA / strip kernels"""
+    c = x0.shape[3] + (0 if x1 is None else x1.shape[3])
+    return (x0.dtype == MX_DTYPE and tuple(stride) == (1, 1) and cout >= 64 and cout % 32 == 0 and c % 32 == 0 and x0.shape[3] % 32 == 0
+            and (ho * wo) % 32 == 0 and not _NO_EPILOGUE_GN)
+
+
+def groupnorm_affine_from_partial(partial, n, h, w, c, gamma, beta, eps=1e-6, valid_w=None):
+    """→ (scale [N,C], shift [N,C]) fp32 from the partial sums a conv epilogue wrote (no pass over the map)"""
+    lib = _lib.load()
+    _need_cuda(partial, gamma, beta, valid_w)
+    scale = torch.empty((n, c), dtype=torch.float32, device=partial.device)
+    shift = torch.empty((n, c), dtype=torch.float32, device=partial.device)
+    _lib.check(lib.mnet_groupnorm_affine_from_partial(_p(partial), n, h, w, c, _p(valid_w), _p(gamma), _p(beta), eps, _p(scale), _p(shift), _stream()),
+               "mnet_groupnorm_affine_from_partial")
+    return scale, shift
+
+
 @_plumbing
 def adain_crop_concat(prior, feat, g_img, g_x1, g_y1, g_w):
     lib = _lib.load()
@@ -299,6 +330,7 @@ def adain_crop_concat(prior, feat, g_img, g_x1, g_y1, g_w):
     return out
 
 
+_NO_EPILOGUE_GN = os.environ.get("MNET_NO_EPILOGUE_GN", "0") == "1"      # A/B knob: GroupNorm statistics by their own pass over the map (round 4)
 ADAIN_SPLIT_BELOW = 256      # glyphs per launch below which the three-launch (16 workgroups per glyph) form is used
 _ADAIN_SPLIT = {"0": False, "1": True}.get(os.environ.get("MNET_ADAIN_SPLIT", ""))     # A/B knob
 

@@ -523,3 +523,81 @@ def test_skip_conv_folded_as_extra_k(storage, case):
     for i in range(n):                    # columns >= valid_w: the two-launch form adds the skip of the UNMASKED x there (never consumed downstream)
         got2[i, :, :, int(vw[i]):] = got[i, :, :, int(vw[i]):]
     assert float((got - got2).abs().max()) / scale <= (4e-3 if storage == "f16" else 1e-4)
+
+
+# ---------------------------------------------------------------------------------------------------------------- round 5
+@pytest.mark.parametrize("case", [
+    # cout, cin, (n, h, w), valid widths or None, tile ids to compare
+    (256, 64, (3, 16, 64), None, (0, 1, 2, 6, 8, 10, 11)),
+    (64, 64, (2, 32, 64), None, (3, 5, 13)),
+    (256, 96, (4, 32, 32), [32, 17, 1, 29], (0, 6, 10, 11)),          # glyph maps: statistics over columns < valid_w only
+    (128, 64, (2, 16, 96), None, (2, 4, 7, 8, 10)),
+])
+def test_groupnorm_partial_sums_from_the_conv_epilogue(case):
+    """round 5 (mnet_conv_desc.gn_partial): the fp16+8 LDS-DMA epilogue writes, per 32 consecutive pixels x 32-channel group, the sum and the sum of
+    squares of its output; mnet_groupnorm_affine_from_partial folds them into the GroupNorm affine — no statistics pass over the map.
+    * the affine equals torch's GroupNorm statistics of the conv's output (and the separate-pass kernel's, up to the storage rounding of the map);
+    * the partial sums are the same BYTES for every tile configuration (fixed fragment, fixed tree): batch-invariant;
+    * the software-pipelined tiles (built without the block) hand the launch to their lock-step forms: same output bytes."""
+    ops = _ops()
+    cout, cin, (n, h, w), vws, ids = case
+    x = _q(_rnd((n, cin, h, w), 131))
+    wt = _rnd((cout, cin, 3, 3), 132, 1.0 / math.sqrt(cin * 9))
+    bias = _rnd((cout,), 133, 0.3)
+    gamma, beta = _rnd((cout,), 134).abs() + 0.5, _rnd((cout,), 135, 0.2)
+    vw = None if vws is None else torch.tensor(vws, dtype=torch.int32).to(DEV)
+    xd, wp = _to_mx(x), _pack_w(wt)
+    parts, outs = [], []
+    for i in ids:
+        part = ops.gn_partial_buffer(n, h, w, cout, DEV)
+        part.fill_(float("nan"))
+        y = ops.conv2d(xd, wp, cout, 3, 3, (1, 1), (1, 1), bias=bias.to(DEV), act=2, valid_w=vw, algo=16 + i, gn_partial=part)
+        torch.cuda.synchronize()
+        assert torch.isfinite(part).all(), "tile id %d left fragments unwritten" % i
+        parts.append(part.cpu())
+        outs.append(y.cpu().view(torch.uint8))
+    for p_, o_ in zip(parts[1:], outs[1:]):
+        assert torch.equal(parts[0], p_) and torch.equal(outs[0], o_)
+    y0 = ops.conv2d(xd, wp, cout, 3, 3, (1, 1), (1, 1), bias=bias.to(DEV), act=2, valid_w=vw)                 # AUTO, no statistics
+    assert torch.equal(y0.cpu().view(torch.uint8), outs[0])
+    if cout >= 128:       # an explicit software-pipelined id with gn_partial runs the lock-step form of the same tile
+        part = ops.gn_partial_buffer(n, h, w, cout, DEV)
+        ys = ops.conv2d(xd, wp, cout, 3, 3, (1, 1), (1, 1), bias=bias.to(DEV), act=2, valid_w=vw, algo=16 + (15 if cout >= 256 else 9), gn_partial=part)
+        assert torch.equal(ys.cpu().view(torch.uint8), outs[0]) and torch.equal(part.cpu(), parts[0])
+    sc, sh = ops.groupnorm_affine_from_partial(parts[0].to(DEV), n, h, w, cout, gamma.to(DEV), beta.to(DEV), 1e-6, vw)
+    sc2, sh2 = ops.groupnorm_affine(y0, gamma.to(DEV), beta.to(DEV), 1e-6, vw)                                    # the separate pass, over the STORED values
+    torch.cuda.synchronize()
+    yf = _from_mx(y0)
+    for i in range(n):
+        v = w if vws is None else vws[i]
+        ref = F.group_norm(yf[i:i + 1, :, :, :v], cout // 32, gamma, beta, 1e-6)
+        got = yf[i:i + 1, :, :, :v] * sc[i].cpu()[None, :, None, None] + sh[i].cpu()[None, :, None, None]
+        _check("GroupNorm from epilogue sums, image %d %s" % (i, case[:2]), got, ref, 3e-4 if v < 4 else 6e-5)
+    assert torch.allclose(sc.cpu(), sc2.cpu(), rtol=3e-4, atol=1e-6) and torch.allclose(sh.cpu(), sh2.cpu(), rtol=3e-4, atol=3e-4)
+
+
+def test_groupnorm_partial_sums_strip_kernel_and_refusals():
+    """cout 64 on >= 65536 pixels: the strip kernel's epilogue is the same code; launches that cannot write the sums are refused with MNET_E_ARG"""
+    ops = _ops()
+    from marconet_amd._lib import MarconetHipError
+    n, h, w, c = 2, 128, 256, 64
+    x = _q(_rnd((n, c, h, w), 141))
+    wt = _rnd((c, c, 3, 3), 142, 1.0 / math.sqrt(c * 9))
+    xd, wp = _to_mx(x), _pack_w(wt)
+    part = ops.gn_partial_buffer(n, h, w, c, DEV)
+    y = ops.conv2d(xd, wp, c, 3, 3, (1, 1), (1, 1), act=2, gn_partial=part)                       # AUTO: strip 64x512
+    part2 = ops.gn_partial_buffer(n, h, w, c, DEV)
+    y2 = ops.conv2d(xd, wp, c, 3, 3, (1, 1), (1, 1), act=2, algo=16 + 5, gn_partial=part2)        # per-tap 64x512 tile
+    torch.cuda.synchronize()
+    assert torch.equal(y.cpu().view(torch.uint8), y2.cpu().view(torch.uint8)) and torch.equal(part.cpu(), part2.cpu())
+    yf = _from_mx(y).double()
+    blk = yf.permute(0, 2, 3, 1).reshape(n * h * w // 32, 32, c // 32, 32)
+    s1, s2 = blk.sum(dim=(1, 3)), (blk * blk).sum(dim=(1, 3))
+    assert torch.allclose(part.cpu()[..., 0].double(), s1, rtol=2e-4, atol=2e-3) and torch.allclose(part.cpu()[..., 1].double(), s2, rtol=2e-4, atol=2e-3)
+    with pytest.raises(MarconetHipError):       # stride 2
+        ops.conv2d(xd, wp, c, 3, 3, (2, 2), (1, 1), gn_partial=ops.gn_partial_buffer(n, h // 2, w // 2, c, DEV))
+    with pytest.raises(MarconetHipError):       # a launch that needs the register-staged kernel (input transform)
+        ops.conv2d(xd, wp, c, 3, 3, (1, 1), (1, 1), in_scale=torch.ones(n, c, device=DEV), gn_partial=part)
+    xf = ops.convert(xd, torch.float16)
+    with pytest.raises(MarconetHipError):       # plain f16 storage
+        ops.conv2d(xf, wt.permute(0, 2, 3, 1).contiguous().half().to(DEV), c, 3, 3, (1, 1), (1, 1), gn_partial=part)
