@@ -96,6 +96,10 @@ __device__ __forceinline__ void dma_epilogue_mx(const ConvArgs& p, const f32x16 
     constexpr int NPX = FP / 2, NB = FC / 4;
     const int h = lane >> 5;
     const int last_pix = p.npix - 1;
+    // ConvArgs::gn_partial, read from the kernel-argument segment once per tile (live inside this epilogue only: two SGPRs held across the slab loop moved
+    // a spill slot of the 256-VGPR tiles onto their hot path)
+    float* gnp = nullptr;
+    if constexpr (GN) gnp = kernarg_gn_partial();
 #pragma unroll
     for (int px = 0; px < NPX; ++px) {
         const int pixb = pix0 + wp * (BP / WP) + px * 32;                   // first pixel of this wave's 32
@@ -152,29 +156,32 @@ __device__ __forceinline__ void dma_epilogue_mx(const ConvArgs& p, const f32x16 
                     for (int q = 0; q < 32; q += 4) { const f32x4 s4 = *reinterpret_cast<const f32x4*>(sp + q); v[q] *= s4[0]; v[q + 1] *= s4[1]; v[q + 2] *= s4[2]; v[q + 3] *= s4[3]; }
                 }
             }
-            // (the pointer is read from the kernel-argument segment HERE — ConvArgs is the kernels' only argument, at offset 0 — instead of living in two
-            //  SGPRs across the slab loop: with 100 SGPRs allocated, one more live pair moved a spill slot and put two scratch reloads on the hot path)
-            float* gnp = nullptr;
-            if constexpr (GN) gnp = kernarg_gn_partial();
+            // GroupNorm statistics of this output (round 5), part 1 — while the 32 values are live: two fp32 sums per lane (the lane holds the 32 channels of
+            // ONE group for one pixel).  The fold over the pixels and the store come at the end of the block, where the fewest values are live.
+            float gs1 = 0.f, gs2 = 0.f;
             if (GN && gnp) {
-                // GroupNorm statistics of this output (round 5): the lane holds the 32 channels of ONE group for one pixel, the 32 lanes of a half hold 32
-                // consecutive pixels of one image (ho*wo % 32 == 0) — two fp32 sums per lane, a fixed xor tree over the half, one 8-byte store.  The tree and
-                // the fragment (32 pixels aligned to 32) are the same in every tile configuration: batch-invariant bits.  The consumer folds the fragments in
-                // fp64 (gn_finalize_frag_kernel): the separate statistics pass over the map (one read of it) is gone.
-                float s1 = 0.f, s2 = 0.f;
 #pragma unroll
-                for (int q = 0; q < 32; ++q) { s1 += v[q]; s2 = fmaf(v[q], v[q], s2); }
-                bool ok = pix < p.npix && co < p.cout;
-                if (p.valid_w) {
-                    const int ow = p.wo_shift >= 0 ? (pix & (p.wo - 1)) : pix % p.wo;
-                    ok = ok && ow < p.valid_w[n_img];
-                }
-                s1 = ok ? s1 : 0.f; s2 = ok ? s2 : 0.f;
-#pragma unroll
-                for (int o = 1; o < 32; o <<= 1) { s1 += __shfl_xor(s1, o, 64); s2 += __shfl_xor(s2, o, 64); }
-                if ((lane & 31) == 0 && pixb < p.npix && co < p.cout)
-                    *reinterpret_cast<f32x2*>(gnp + ((size_t)(pixb >> 5) * (p.cout >> 5) + (co >> 5)) * 2) = f32x2{s1, s2};
+                for (int q = 0; q < 32; ++q) { gs1 += v[q]; gs2 = fmaf(v[q], v[q], gs2); }
             }
+            auto gn_finish = [&]() __attribute__((always_inline)) {
+              if constexpr (GN) {
+                // part 2: the 32 lanes of a half hold 32 consecutive pixels of one image (ho*wo % 32 == 0) — a fixed xor tree over the half, one 8-byte store.
+                // The tree and the fragment (32 pixels aligned to 32) are the same in every tile configuration: batch-invariant bits.  The consumer folds the
+                // fragments in fp64 (gn_finalize_frag_kernel): the separate statistics pass over the map (one read of it) is gone.
+                if (gnp) {
+                    bool ok = pix < p.npix && co < p.cout;
+                    if (p.valid_w) {
+                        const int ow = p.wo_shift >= 0 ? (pix & (p.wo - 1)) : pix % p.wo;
+                        ok = ok && ow < p.valid_w[n_img];
+                    }
+                    gs1 = ok ? gs1 : 0.f; gs2 = ok ? gs2 : 0.f;
+#pragma unroll
+                    for (int o = 1; o < 32; o <<= 1) { gs1 += __shfl_xor(gs1, o, 64); gs2 += __shfl_xor(gs2, o, 64); }
+                    if ((lane & 31) == 0 && pixb < p.npix && co < p.cout)
+                        *reinterpret_cast<f32x2*>(gnp + ((size_t)(pixb >> 5) * (p.cout >> 5) + (co >> 5)) * 2) = f32x2{gs1, gs2};
+                }
+              }
+            };
             if (!xpose && pix >= p.npix) continue;
             f16x8 hh[4];
             float m32 = 0.f;
@@ -196,6 +203,7 @@ __device__ __forceinline__ void dma_epilogue_mx(const ConvArgs& p, const f32x16 
                 stg16(yb + 80, u32x4{lo[1][0], lo[1][1], lo[3][0], lo[3][1]});
                 stg16(yb + 96, u32x4{(unsigned)e8, 0u, 0u, 0u});
                 stg16(yb + 112, u32x4{0u, 0u, 0u, 0u});
+                gn_finish();
                 continue;
             }
             // (hm_encode_lo_ref / act_apply_vec, not the mixed-precision VALU forms of common.h: with them this epilogue executes ~25 % fewer VALU
@@ -253,6 +261,7 @@ __device__ __forceinline__ void dma_epilogue_mx(const ConvArgs& p, const f32x16 
                     }
                 }
             }
+            gn_finish();
         }
     }
 }

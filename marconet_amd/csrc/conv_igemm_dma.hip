@@ -522,6 +522,10 @@ __global__ void __launch_bounds__(WC * WP * 64, WC * WP / 4) conv_dma_kernel(con
 
 
     if constexpr (SWP) {
+#ifndef MNET_SWP_GN
+#define MNET_SWP_GN 0
+#endif
+        constexpr bool SWP_GN = MNET_SWP_GN != 0;           // the GroupNorm partial sums in the software-pipelined tiles' epilogue: see dma_epilogue_mx / launch_conv_dma
         constexpr int FA = FC / 2, FB = FP / 2;
 #if defined(MNET_SWP_PRIO) && MNET_SWP_PRIO == 1
         if (wave >= NW / 2) __builtin_amdgcn_s_setprio(1);              // A/B build: static priority for the later-dispatched wave of every SIMD
@@ -731,7 +735,7 @@ __global__ void __launch_bounds__(WC * WP * 64, WC * WP / 4) conv_dma_kernel(con
             if (c_kt == nk) {                                            // slab s-1 closed its tile: epilogue, then the next tile's scales and a clean accumulator
                 int co0, pix0;
                 tile_coords(c_v, co0, pix0);
-                dma_epilogue_mx<BC, BP, WC, WP, FC, FP, (XB == 1024 ? 16 : 64), false>(p, acc32, co0, pix0, wc, wp, lane, xpose);
+                dma_epilogue_mx<BC, BP, WC, WP, FC, FP, (XB == 1024 ? 16 : 64), SWP_GN>(p, acc32, co0, pix0, wc, wp, lane, xpose);
                 c_kt = 0; c_v += G;
                 if (p.tilesC > 1) load_scales(c_v);                      // (one channel tile: every tile has the same scales)
                 zero_acc();
@@ -748,7 +752,7 @@ __global__ void __launch_bounds__(WC * WP * 64, WC * WP / 4) conv_dma_kernel(con
         {
             int co0, pix0;
             tile_coords(c_v, co0, pix0);
-            dma_epilogue_mx<BC, BP, WC, WP, FC, FP, (XB == 1024 ? 16 : 64), false>(p, acc32, co0, pix0, wc, wp, lane, xpose);
+            dma_epilogue_mx<BC, BP, WC, WP, FC, FP, (XB == 1024 ? 16 : 64), SWP_GN>(p, acc32, co0, pix0, wc, wp, lane, xpose);
         }
         if constexpr (DBG == 6) {       // DIAGNOSTIC: phase sums of this wave over the first bytes of the output (32 bytes per wave)
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
