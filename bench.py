@@ -618,6 +618,9 @@ def main():
             del t_pipe, t_nets
         par["regimes"] = "tame (default synthetic, all sr_max_abs_* above) and trained_like (heavy-tailed weights, modulation spread 1e3, SN sigma in [0.1,10])"
         par["bar"] = "north_star: <= 1e-3 max-abs on the SR output, argmax bit-exact (argmax_match == 1.0)"
+        par["oracle"] = ("oracle/marconet_oracle.py = CPU restatement of models/*.py, pinned against the real reference modules in the build container (<= 1e-6) and by "
+                         "tests/golden; unpinned by the reference itself: basicsr fused_act (un-vendored; upstream semantics sqrt2*lrelu(x+b)); cv2 INTER_CUBIC is outside "
+                         "this forward; cpu_baseline.kind = port (the oracle: /root/reference does not travel to the GPU box)")
         out["parity"] = par
     elif rank == 0 and world == 1 and a.cpu_images > 0 and a.config == "gan":
         from oracle import marconet_oracle as O
