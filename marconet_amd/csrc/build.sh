@@ -11,16 +11,18 @@ if [ "${MNET_CLEAN:-0}" != "0" ]; then rm -f "$OUT"/*.o "$OUT"/*.o.tmp "$OUT"/*.
 HIPCC="${HIPCC:-/opt/rocm/bin/hipcc}"
 PIDS=()
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-function"
-SRCS="api conv_igemm conv_igemm_dma conv_strip_dma conv_skinny aux_kernels vit_kernels pack_kernels"
+SRCS="api conv_igemm conv_igemm_dma conv_dma_swp_gn conv_strip_dma conv_skinny aux_kernels vit_kernels pack_kernels"
+# per-source extra flags (conv_dma_swp_gn: see the note at its top)
+extra() { case "$1" in conv_dma_swp_gn) echo "-mllvm -greedy-reverse-local-assignment=1" ;; *) echo "" ;; esac; }
 HDRS="$HERE/common.h $HERE/conv_args.h $HERE/conv_dma_common.h $HERE/../../include/marconet_hip.h"
 CCVER="$("$HIPCC" --version 2>/dev/null | head -3 | tr '\n' ' ')"
-stamp() { { cat "$HERE/$1.hip" $HDRS; echo "$FLAGS ${EXTRA_HIPCC_FLAGS:-} | $CCVER"; } | sha256sum | cut -d' ' -f1; }
+stamp() { { cat "$HERE/$1.hip" $HDRS; [ "$1" = conv_dma_swp_gn ] && cat "$HERE/conv_igemm_dma.hip"; echo "$FLAGS $(extra "$1") ${EXTRA_HIPCC_FLAGS:-} | $CCVER"; } | sha256sum | cut -d' ' -f1; }
 for f in $SRCS; do
   want="$(stamp "$f")"
   if [ ! -f "$OUT/$f.o" ] || [ ! -f "$OUT/$f.o.sha" ] || [ "$(cat "$OUT/$f.o.sha")" != "$want" ]; then
     echo "[build] hipcc $f.hip"
     rm -f "$OUT/$f.o.sha"
-    ( "$HIPCC" $FLAGS ${EXTRA_HIPCC_FLAGS:-} -c "$HERE/$f.hip" -o "$OUT/$f.o.tmp" && mv "$OUT/$f.o.tmp" "$OUT/$f.o" && echo "$want" > "$OUT/$f.o.sha" ) &
+    ( "$HIPCC" $FLAGS $(extra "$f") ${EXTRA_HIPCC_FLAGS:-} -c "$HERE/$f.hip" -o "$OUT/$f.o.tmp" && mv "$OUT/$f.o.tmp" "$OUT/$f.o" && echo "$want" > "$OUT/$f.o.sha" ) &
     PIDS+=($!)
   fi
 done

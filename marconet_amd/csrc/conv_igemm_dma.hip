@@ -50,7 +50,10 @@
 //     MFMAs.  Per output the order stays f16 k-step 0, f16 k-step 1, scaled fp8 of slab 0, then slab 1, ...: the bytes equal the other fp16+8 tiles'.
 //     LDS hazards: slab s-1's stage is last read (fp8-side operands) during the f16 MFMAs of iteration s-1, before barrier(s); the DMA of slab
 //     s+1 into that stage starts after barrier(s).
-template <int BC, int BP, int WC, int WP, int STAGES, int MF = 16, int DBG = 0, bool X3 = false, bool SPREAD = false, bool PIPE = false, bool MX = false, bool SWP = false>
+// SGN (with SWP): the software-pipelined tile WITH the GroupNorm-sum block in its epilogue.  Only conv_dma_swp_gn.hip instantiates it — a translation unit of its own,
+//     compiled with `-mllvm -greedy-reverse-local-assignment=1`: with hipcc's default assignment order that block moves a spill of the slab loop onto its hot path (three
+//     formulations tried), with the reverse order the tile is clean (31 spilled registers, none hot: tools/isa_hot_scratch.py).  The flag is kept away from every other tile.
+template <int BC, int BP, int WC, int WP, int STAGES, int MF = 16, int DBG = 0, bool X3 = false, bool SPREAD = false, bool PIPE = false, bool MX = false, bool SWP = false, bool SGN = false>
 __global__ void __launch_bounds__(WC * WP * 64, WC * WP / 4) conv_dma_kernel(const ConvArgs p) {
     constexpr int NW = WC * WP;                          // waves per workgroup (8 or 16)
     constexpr int FC = BC / WC / 16, FP = BP / WP / 16;
@@ -62,6 +65,7 @@ __global__ void __launch_bounds__(WC * WP * 64, WC * WP / 4) conv_dma_kernel(con
     constexpr unsigned OOB = 0x80000000u;                // beyond every num_records used below
     static_assert(NW == 8 || NW == 16, "8 or 16 waves");
     static_assert(!MX || (X3 && MF == 32), "MX: 4-byte storage, 32x32 MFMAs");
+    static_assert(!SGN || SWP, "SGN: software-pipelined tiles only");
     static_assert(!SWP || (MX && NW == 8 && STAGES == 2 && (DBG == 0 || DBG == 6) && (FC / 2) * (FP / 2) <= 16 && NDMA <= 16), "SWP: fp16+8, 2 stages, <= 16 accumulator blocks per wave");
     static_assert(!SPREAD || (STAGES == 2 && (MF == 16 || X3) && (DBG == 0 || DBG == 6)), "SPREAD: production 2-stage tiles only");
     static_assert(WJ >= 1 && XJ >= 1 && WJ * 8 * NWI == BC && XJ * 8 * NWI == BP, "tile / wave-count mismatch");
@@ -522,10 +526,7 @@ __global__ void __launch_bounds__(WC * WP * 64, WC * WP / 4) conv_dma_kernel(con
 
 
     if constexpr (SWP) {
-#ifndef MNET_SWP_GN
-#define MNET_SWP_GN 0
-#endif
-        constexpr bool SWP_GN = MNET_SWP_GN != 0;           // the GroupNorm partial sums in the software-pipelined tiles' epilogue: see dma_epilogue_mx / launch_conv_dma
+        constexpr bool SWP_GN = SGN;                        // the GroupNorm partial sums in the software-pipelined tile's epilogue: see the SGN note above the kernel
         constexpr int FA = FC / 2, FB = FP / 2;
 #if defined(MNET_SWP_PRIO) && MNET_SWP_PRIO == 1
         if (wave >= NW / 2) __builtin_amdgcn_s_setprio(1);              // A/B build: static priority for the later-dispatched wave of every SIMD
@@ -882,10 +883,10 @@ __global__ void __launch_bounds__(WC * WP * 64, WC * WP / 4) conv_dma_kernel(con
     }
 }
 
-template <int BC, int BP, int WC, int WP, int STAGES, int MF = 16, int DBG = 0, bool X3 = false, bool SPREAD = false, bool PIPE = false, bool MX = false, bool SWP = false>
+template <int BC, int BP, int WC, int WP, int STAGES, int MF = 16, int DBG = 0, bool X3 = false, bool SPREAD = false, bool PIPE = false, bool MX = false, bool SWP = false, bool SGN = false>
 static int launch_dma_cfg(const ConvArgs& a, hipStream_t st) {
     constexpr int LDS = STAGES * (BC + BP) * 128 + WC * WP * dma_mx_xpose_bytes<WC * WP, MX>(STAGES * (BC + BP) * 128);
-    auto kern = conv_dma_kernel<BC, BP, WC, WP, STAGES, MF, DBG, X3, SPREAD, PIPE, MX, SWP>;
+    auto kern = conv_dma_kernel<BC, BP, WC, WP, STAGES, MF, DBG, X3, SPREAD, PIPE, MX, SWP, SGN>;
     static thread_local DeviceOnce attr_once;      // per instantiation, per thread, per device
     if (!attr_once.done()) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
@@ -906,6 +907,12 @@ static int launch_dma_cfg(const ConvArgs& a, hipStream_t st) {
     MNET_LAUNCH_CHECK("conv_dma_kernel");
     return MNET_OK;
 }
+
+#ifdef MNET_DMA_SWP_GN_TU
+// conv_dma_swp_gn.hip: this translation unit holds ONE instantiation — the software-pipelined 256x256 fp16+8 tile with the GroupNorm-sum block
+int launch_dma_swp_gn(const ConvArgs& a, hipStream_t st) { return launch_dma_cfg<256, 256, 2, 4, 2, 32, 0, true, false, false, true, true, true>(a, st); }
+#else
+int launch_dma_swp_gn(const ConvArgs& a, hipStream_t st);      // conv_dma_swp_gn.hip
 
 // tile configurations (BC x BP, waves, LDS stages, MFMA shape); MNET_CONV_ALGO_DMA_CFG0 + id selects one explicitly.
 // Production ids 0-6 all use v_mfma_f32_16x16x32_f16 and walk k in the same order (64-channel slice outer, tap inner), so a
@@ -1022,8 +1029,9 @@ int conv_dma_pick(const ConvArgs& a) {
         // placed by scheduling hints) on the four shapes that carry the step, +1.2 % end to end, same bytes (profiles/r4g_*)
         static const int env_mx_256 = [] { const char* e = getenv("MNET_MX_CFG256"); return e ? atoi(e) : 15; }();
         static const int env_mx_128 = [] { const char* e = getenv("MNET_MX_CFG128"); return e ? atoi(e) : 8; }();
-        // (launches that write GroupNorm partial sums take the lock-step forms 11 / 8 of the software-pipelined tiles 15 / 9: see launch_conv_dma)
-        const auto no_swp = [&](int id) { return a.gn_partial ? (id == 15 ? 11 : (id == 9 ? 8 : id)) : id; };
+        // (launches that write GroupNorm partial sums: id 15 runs its SGN build, conv_dma_swp_gn.hip; the software-pipelined 128x512 tile has no such build → its lock-step form 8)
+        static const int env_gn_lockstep = [] { const char* e = getenv("MNET_GN_LOCKSTEP"); return e ? atoi(e) : 0; }();     // A/B knob: 1 = round-5's first form (id 15 → 11)
+        const auto no_swp = [&](int id) { return a.gn_partial ? (id == 15 && env_gn_lockstep ? 11 : (id == 9 ? 8 : id)) : id; };
         if (a.cout >= 256) return big ? no_swp(env_mx_256) : (t128 * ((a.cout + 255) / 256) < 200 ? 10 : 1);
         if (a.cout >= 128) return big ? no_swp(env_mx_128) : (t256 * ((a.cout + 127) / 128) < 200 ? 10 : 2);
         static const int env_mx_64 = [] { const char* e = getenv("MNET_MX_CFG64"); return e ? atoi(e) : 13; }();       // id 13 = id 5 + hints: 260 vs 251
@@ -1043,9 +1051,12 @@ int conv_dma_pick(const ConvArgs& a) {
 
 int launch_conv_dma(const ConvArgs& a, hipStream_t st, int cfg) {
     int id = cfg >= 0 ? cfg : conv_dma_pick(a);
-    // launches that write GroupNorm partial sums: the software-pipelined tiles are built without that block (dma_epilogue_mx<..., GN = false>) —
-    // their lock-step forms take over (id 15 -> 11, id 9 -> 8: the same tile shapes, the same MFMA sequence, the same bytes)
-    if (a.gn_partial && a.split == 2) id = id == 15 ? 11 : (id == 9 ? 8 : id);
+    // launches that write GroupNorm partial sums: the software-pipelined tiles of THIS translation unit are built without that block (dma_epilogue_mx<..., GN = false>);
+    // id 15 has a build with it in conv_dma_swp_gn.hip, id 9 hands over to its lock-step form 8 (the same tile shape, the same MFMA sequence, the same bytes)
+    if (a.gn_partial && a.split == 2) {
+        if (id == 15) return launch_dma_swp_gn(a, st);
+        if (id == 9) id = 8;
+    }
     return launch_dma_id(id, a, st);
 }
 
@@ -1063,4 +1074,4 @@ bool conv_dma_eligible(const ConvArgs& a, int dtype) {
     if ((long long)a.cout * a.K * 2 >= 0x7fffffffLL) return false;
     return true;
 }
-
+#endif  // MNET_DMA_SWP_GN_TU

@@ -25,3 +25,14 @@ def test_dominant_tile_has_no_scratch_access_in_its_slab_loop(tmp_path):
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "isa_hot_scratch.py"), asm], capture_output=True, text=True, timeout=120)
     print(r.stdout)
     assert "scratch accesses on the hot path: 0" in r.stdout and r.returncode == 0, r.stdout + r.stderr
+    # round 5: the build of the same tile WITH the GroupNorm-sum block — its own translation unit, compiled with the flag build.sh gives it (without the flag
+    # hipcc puts scratch reloads into its slab loop)
+    asm2 = str(tmp_path / "conv_dma_swp_gn.s")
+    r = subprocess.run([cc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-mllvm", "-greedy-reverse-local-assignment=1", "-S", "--cuda-device-only",
+                        os.path.join(ROOT, "marconet_amd", "csrc", "conv_dma_swp_gn.hip"), "-o", asm2], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "isa_hot_scratch.py"), asm2], capture_output=True, text=True, timeout=120)
+    print(r.stdout)
+    assert "ELb1ELb1EEv8ConvArgs" in r.stdout and "scratch accesses on the hot path: 0" in r.stdout and r.returncode == 0, r.stdout + r.stderr
+    flag = open(os.path.join(ROOT, "marconet_amd", "csrc", "build.sh")).read()
+    assert "conv_dma_swp_gn) echo \"-mllvm -greedy-reverse-local-assignment=1\"" in flag, "build.sh must compile conv_dma_swp_gn.hip with the flag this test checks"

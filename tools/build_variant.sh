@@ -9,13 +9,14 @@ NAME=$1; STEM=$2; shift 2
 SRC="$ROOT/marconet_amd/csrc"; LIB="$ROOT/marconet_amd/lib"; OUT="$ROOT/tools/_build/$NAME"
 mkdir -p "$OUT"
 HIPCC="${HIPCC:-/opt/rocm/bin/hipcc}"
-ALL="api conv_igemm conv_igemm_dma conv_strip_dma conv_skinny aux_kernels vit_kernels pack_kernels"
+ALL="api conv_igemm conv_igemm_dma conv_dma_swp_gn conv_strip_dma conv_skinny aux_kernels vit_kernels pack_kernels"
+xf() { [ "$1" = conv_dma_swp_gn ] && echo "-mllvm -greedy-reverse-local-assignment=1"; }
 if [ "$STEM" = "all" ]; then
   PIDS=()
-  for f in $ALL; do ( "$HIPCC" --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-function "$@" -c "$SRC/$f.hip" -o "$OUT/$f.o" 2>/dev/null ) & PIDS+=($!); done
+  for f in $ALL; do ( "$HIPCC" --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-function $(xf "$f") "$@" -c "$SRC/$f.hip" -o "$OUT/$f.o" 2>/dev/null ) & PIDS+=($!); done
   for p in "${PIDS[@]}"; do wait "$p"; done
 else
-  "$HIPCC" --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-function "$@" -c "$SRC/$STEM.hip" -o "$OUT/$STEM.o"
+  "$HIPCC" --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-function $(xf "$STEM") "$@" -c "$SRC/$STEM.hip" -o "$OUT/$STEM.o"
 fi
 OBJS=""
 for f in $ALL; do

@@ -10,8 +10,9 @@ cp -r "$ROOT/marconet_amd/csrc" "$W/src/marconet_amd/csrc"; cp "$ROOT/include/"*
 ( cd "$W/src" && patch -p1 --quiet < "$PATCH" )
 HIPCC="${HIPCC:-/opt/rocm/bin/hipcc}"
 PIDS=()
-for f in api conv_igemm conv_igemm_dma conv_strip_dma conv_skinny aux_kernels vit_kernels pack_kernels; do
-  ( "$HIPCC" --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-function "$@" -c "$W/src/marconet_amd/csrc/$f.hip" -o "$W/$f.o" ) &
+xf() { [ "$1" = conv_dma_swp_gn ] && echo "-mllvm -greedy-reverse-local-assignment=1"; }
+for f in api conv_igemm conv_igemm_dma conv_dma_swp_gn conv_strip_dma conv_skinny aux_kernels vit_kernels pack_kernels; do
+  ( "$HIPCC" --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-function $(xf "$f") "$@" -c "$W/src/marconet_amd/csrc/$f.hip" -o "$W/$f.o" ) &
   PIDS+=($!)
 done
 for p in "${PIDS[@]}"; do wait "$p"; done

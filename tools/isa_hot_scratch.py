@@ -8,11 +8,13 @@ MFMAs and counts scratch accesses outside the region the hot path branches aroun
 
     hipcc --offload-arch=gfx950 -O3 -std=c++17 -S --cuda-device-only marconet_amd/csrc/conv_igemm_dma.hip -o /tmp/dma.s
     python tools/isa_hot_scratch.py /tmp/dma.s [mangled-name substring ...]     (default: the fp16+8 256x256 software-pipelined tile)
+    hipcc ... -mllvm -greedy-reverse-local-assignment=1 -S --cuda-device-only marconet_amd/csrc/conv_dma_swp_gn.hip -o /tmp/sgn.s; python tools/isa_hot_scratch.py /tmp/sgn.s
+        (the build of that tile with the GroupNorm-sum block: its own translation unit and flag, marconet_amd/csrc/build.sh)
 exit status 1 if any hot scratch access is found."""
 import re
 import sys
 
-DEFAULT = ["conv_dma_kernelILi256ELi256ELi2ELi4ELi2ELi32ELi0ELb1ELb0ELb0ELb1ELb1E"]
+DEFAULT = ["conv_dma_kernelILi256ELi256ELi2ELi4ELi2ELi32ELi0ELb1ELb0ELb0ELb1ELb1E"]      # (both builds: ...ELb0E = production, ...ELb1E = with the GroupNorm-sum block, conv_dma_swp_gn.hip)
 
 
 def check(s, name):
