@@ -373,6 +373,8 @@ def main():
         step()
     # headline: the product's default configuration, un-instrumented
     dt, per_rank_dt, y = timed(step, fence, a.steps, world, dev)
+    # HBM in use by the timed workload (inputs, weights, every live activation; torch's caching allocator is the only allocator on the path)
+    hbm_peak_gb = round(torch.cuda.max_memory_allocated(dev) / 1e9, 1)
     # roofline of the dominant kernel: a SEPARATE pass with HIP events around every conv launch (same stream)
     prof_steps = min(a.steps, 2)
     roofline, peak = instrumented(step, prof_steps, alg_gf_step, B if a.config == "sr" else None, a.precision)
@@ -469,7 +471,7 @@ def main():
                    "prior_image_note": ("TSPGAN's 128-px level (%.0f of %.0f GF/img) feeds only the structure image forward_batch discards: computed, in %s"
                                         % (GF_GAN_IMAGE_LEVEL * n, gf_image, img_prec)) if a.config == "sr" else None,
                    "gflop_per_image": round(gf_image, 1), "gflop_per_image_by_arithmetic": arithmetic,
-                   "weights": weights_source,
+                   "weights": weights_source, "hbm_peak_gb": hbm_peak_gb, "hbm_capacity_gb": 288,
                    "collective": (("RCCL world of %d: " % world) + "all_gather(%s), asynchronous, overlapped with the next step"
                                   % ("uint8 BGR post-processed SR [b,128,2048,3]" if u8 else "fp32 SR outputs [b,3,128,2048]"))
                    if gather is not None else "none"},

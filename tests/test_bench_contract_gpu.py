@@ -29,6 +29,7 @@ def test_default_line_has_the_contract_fields():
     for k in ("workload", "per_gpu_batch", "global_batch", "glyphs_per_image", "parallelism", "precision_mode", "need_prior_image", "prior_image_precision",
               "gflop_per_image", "gflop_per_image_by_arithmetic", "weights"):
         assert k in cfg, k
+    assert 0.5 < cfg["hbm_peak_gb"] < cfg["hbm_capacity_gb"] == 288     # what the timed workload holds in HBM (batch 8 here: a few GB)
     assert "model" not in cfg and len(cfg["workload"]) <= 128          # (the driver's parsed record cuts strings at 128 characters)
     r = d["roofline"]
     for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "kernel", "hbm_tail_ms_per_step", "all_conv_achieved"):
