@@ -410,7 +410,7 @@ def main():
         secondary["images_per_s_without_prior_image"] = round(total_images * sec_steps / dt2, 3)
         secondary["note_without_prior_image"] = "opt-in MarconetPipeline(need_prior_image=False): TSPGAN stops at the 64-px level; SR output identical"
         if pipe._image_precision() not in (None, a.precision):
-            # the default runs TSPGAN's image-only 128-px level (11.5 % of the algorithmic FLOPs; forward_batch never returns that image) in plain
+            # the default runs TSPGAN's image-only 128-px level (11.5 % of the algorithmic FLOPs; forward_batch drops that image unless return_prior=True) in plain
             # fp16: here the same step with EVERY level in the mode's own arithmetic (prior_image_precision=None)
             saved = pipe.prior_image_precision
             pipe.prior_image_precision = None
@@ -468,7 +468,7 @@ def main():
                    "parallelism": "dp%d" % world, "precision_mode": a.precision,
                    "need_prior_image": bool(pipe.need_prior_image) if a.config != "gan" else True,
                    "prior_image_precision": img_prec,
-                   "prior_image_note": ("TSPGAN's 128-px level (%.0f of %.0f GF/img) feeds only the structure image forward_batch discards: computed, in %s"
+                   "prior_image_note": ("TSPGAN's 128-px level (%.0f of %.0f GF/img) feeds only the structure image, dropped here (return_prior=False): computed, in %s"
                                         % (GF_GAN_IMAGE_LEVEL * n, gf_image, img_prec)) if a.config == "sr" else None,
                    "gflop_per_image": round(gf_image, 1), "gflop_per_image_by_arithmetic": arithmetic,
                    "weights": weights_source, "hbm_peak_gb": hbm_peak_gb, "hbm_capacity_gb": 288,

@@ -257,7 +257,7 @@ class TextGenerator(nn.Module):
         the producing conv itself (the batched driver hands slices of its all-glyph buffers: no concatenation pass afterwards).
         ``need_image=False`` (opt-in, batched SR driver only) stops after the 64-px level: the 128-px level feeds nothing
         but the visualisation image (models/networks.py:148-164; 35 % of the generator's FLOPs) and ``image`` is None.
-        ``image_precision`` (batched SR driver only, which never returns ``image``): precision mode of the levels BEHIND the two
+        ``image_precision`` (batched SR driver only, for an image it drops — its ``return_prior=True`` form keeps the mode's arithmetic): precision mode of the levels BEHIND the two
         prior levels — they feed nothing but the structure image (:161-164), so the driver keeps the reference's work but does not
         spend SR-grade arithmetic on it; prior64 / prior32 (and hence the SR output) are bit-identical with and without it."""
         pk = self._cache.get(self, self.precision, self._build)

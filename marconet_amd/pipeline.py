@@ -35,7 +35,7 @@ class MarconetPipeline:
         # True (default): the generator also produces its 128-px structure image, as test_sr.py:183 does (it is only ever
         # used for the saved visualisation, test_sr.py:203-232).  False is an opt-in for throughput serving.
         self.need_prior_image = need_prior_image
-        # precision mode of the generator levels that feed only that image (forward_batch never returns it): "auto" = plain fp16 in
+        # precision mode of the generator levels that feed only that image (while forward_batch drops it; ``return_prior=True`` returns it, in the mode's arithmetic): "auto" = plain fp16 in
         # the fp16x2 / fp16x3 modes, the mode's own arithmetic otherwise; None = always the mode's own.  The priors and the SR output
         # do not depend on it (tests/test_modules_gpu.py::test_prior_image_precision_leaves_sr_bits_unchanged)
         self.prior_image_precision = prior_image_precision
@@ -56,19 +56,26 @@ class MarconetPipeline:
         return self
 
     @torch.no_grad()
-    def forward_batch(self, lq, labels, locs, return_nhwc=False, output="nchw_f32"):
+    def forward_batch(self, lq, labels, locs, return_nhwc=False, output="nchw_f32", return_prior=False):
         """lq [B,3,32,512] fp32 (device); labels: list of B int64 [n_b,1] tensors; locs [B, ≥2·max n_b] fp32 — labels and
         locs on the device or (preferably: no synchronisation then) on the host.
         → SR [B,3,128,2048] fp32 NCHW (the reference's return), or NHWC [B,128,2048,8] in the compute dtype if return_nhwc,
         or — output="u8_bgr" — the script's post-processed image [B,128,2048,3] uint8 BGR (test_sr.py:198-200; 4x fewer bytes
-        to copy to the host or to all-gather)."""
+        to copy to the host or to all-gather).
+        ``return_prior=True`` → ``(that, prior_cha)``: the generator's structure images of all glyphs, fp32 NCHW [ΣN,3,128,128] in
+        strip order — what test_sr.py:183 names ``prior_cha`` and :207-212 turn into the panel's last row.  The levels behind the two
+        prior levels then run in the MODE's arithmetic (``prior_image_precision="auto"`` demotes them to plain fp16 only while the
+        image is dropped), so the returned image holds the same bar as ``TSPGAN.forward``'s; the SR output is the same bits either way."""
         dev = lq.device
         counts = [int(l.shape[0]) for l in labels]
+        if return_prior and not self.need_prior_image:
+            raise ValueError("return_prior=True needs MarconetPipeline(need_prior_image=True): the 128-px level is what produces the image")
         with ops.on_device(lq):
             lab, img_of = self._host_prep(labels, counts, dev)
-            y = self._core(lq, lab, img_of, counts, locs, None, return_nhwc, output)
+            prior = torch.empty((sum(counts), 128, 128, 4), dtype=torch.float32, device=dev) if return_prior else None
+            y = self._core(lq, lab, img_of, counts, locs, None, return_nhwc, output, prior_images=prior)
             self._raise_if_not_finite()
-            return y
+            return (y, ops.nhwc_to_nchw(prior, c=3) if sum(counts) else prior.new_zeros((0, 3, 128, 128))) if return_prior else y
 
     def _raise_if_not_finite(self):
         """half-range modes (fp16 / fp16x3 / fp16x2 store |activation| < 65504): an overflow turns into NaN on its way through the
@@ -92,8 +99,9 @@ class MarconetPipeline:
         return lab.to(dev).contiguous(), torch.repeat_interleave(torch.arange(len(counts)), torch.tensor(counts)).to(dev)
 
     @torch.no_grad()
-    def _core(self, lq, lab, img_of, counts, locs, tables, return_nhwc=False, output="nchw_f32"):
-        """the device-side part of forward_batch: nothing here touches host data (it can be captured in a HIP graph)"""
+    def _core(self, lq, lab, img_of, counts, locs, tables, return_nhwc=False, output="nchw_f32", prior_images=None):
+        """the device-side part of forward_batch: nothing here touches host data (it can be captured in a HIP graph).
+        ``prior_images`` (fp32 [ΣN,128,128,4] or None): filled with the generator's structure images, chunk by chunk"""
         _, _, w = self.encoder(lq)                                    # test_sr.py:146
         tg = self.gan.TextGenerator
         tg.precision = self.precision
@@ -104,14 +112,18 @@ class MarconetPipeline:
             G, gdt = lab.shape[0], torch_dtype(tg.precision)
             p64 = new_tensor((G, 64, 64, 256), gdt, lq.device)
             p32 = new_tensor((G, 32, 32, 512), gdt, lq.device)
+            # a returned image is computed in the mode's arithmetic; a dropped one under ``prior_image_precision`` (see forward_batch)
+            img_prec = self._image_precision() if prior_images is None or self.prior_image_precision != "auto" else None
             for s in range(0, G, self.glyph_chunk):
                 e = min(G, s + self.glyph_chunk)
                 if _NO_STYLE_DEDUPE:
-                    tg.forward_nhwc(w.index_select(0, img_of[s:e]).contiguous(), lab[s:e].contiguous(),
-                                    need_image=self.need_prior_image, p64_out=p64[s:e], p32_out=p32[s:e], image_precision=self._image_precision())
-                    continue
-                tg.forward_nhwc(w, lab[s:e].contiguous(), need_image=self.need_prior_image, style_index=img_of[s:e].contiguous(),
-                                p64_out=p64[s:e], p32_out=p32[s:e], image_precision=self._image_precision())
+                    img = tg.forward_nhwc(w.index_select(0, img_of[s:e]).contiguous(), lab[s:e].contiguous(),
+                                          need_image=self.need_prior_image, p64_out=p64[s:e], p32_out=p32[s:e], image_precision=img_prec)[0]
+                else:
+                    img = tg.forward_nhwc(w, lab[s:e].contiguous(), need_image=self.need_prior_image, style_index=img_of[s:e].contiguous(),
+                                          p64_out=p64[s:e], p32_out=p32[s:e], image_precision=img_prec)[0]
+                if prior_images is not None:
+                    prior_images[s:e].copy_(img)
             sr_dtype = torch_dtype(self.sr.precision)                 # the three nets may run in different precision modes
             p64, p32 = ops.convert(p64, sr_dtype), ops.convert(p32, sr_dtype)
         else:
@@ -224,12 +236,15 @@ class MarconetPipeline:
         return all_gather_outputs(y, B, group, force=force_collective)
 
     @torch.no_grad()
-    def restore_strips(self, strips):
+    def restore_strips(self, strips, with_prior=False):
         """The body of test_sr.py's ``for img_name`` loop (:77-201) for a list of strips prepared by ``lq_io.strip_from_png``
         (dicts with lq [1,3,32,512], labels int64 [n,1], locs [1,2n], show_w) — as ONE batch.  → list of uint8 BGR arrays
         [128, show_w, 3] on the host (``ShowSR``, test_sr.py:198-201: the post-processed SR result cropped to the content
         width); ``None`` for a strip the script would skip (a character outside the alphabet → label −1 → the generator
-        raises, test_sr.py:181-190; no character at all, :168-170)."""
+        raises, test_sr.py:181-190; no character at all, :168-170).
+        ``with_prior=True`` → list of ``(ShowSR, prior128)``: ``prior128`` = the strip's structure images side by side, float32 RGB
+        [128, 128·n, 3] = ``np.hstack`` of ``prior_cha * 0.5 + 0.5`` (test_sr.py:208-211) — the array the script hands to ``cv2.resize``
+        for the panel's last row (:212; cv2 is not part of this build, the resize stays with the caller)."""
         dev = next(self.sr.parameters()).device
         n_cls = self.gan.TextGenerator.class_num
         keep = [i for i, s in enumerate(strips)
@@ -242,9 +257,18 @@ class MarconetPipeline:
         for k, i in enumerate(keep):
             locs[k, :strips[i]["locs"].shape[1]] = strips[i]["locs"][0]
         lq = torch.cat([strips[i]["lq"] for i in keep]).to(dev)
-        y = self.forward_batch(lq, [strips[i]["labels"] for i in keep], locs, output="u8_bgr").cpu().numpy()
+        y = self.forward_batch(lq, [strips[i]["labels"] for i in keep], locs, output="u8_bgr", return_prior=with_prior)
+        if with_prior:
+            y, prior = y
+            prior = (prior * 0.5 + 0.5).permute(0, 2, 3, 1).cpu().numpy()            # test_sr.py:208
+        y = y.cpu().numpy()
+        g = 0
         for k, i in enumerate(keep):
             out[i] = y[k, :, :strips[i]["show_w"], :]
+            if with_prior:
+                n = int(strips[i]["labels"].shape[0])
+                out[i] = (out[i], prior[g:g + n].transpose(1, 0, 2, 3).reshape(128, 128 * n, 3))   # hstack of the n images (:209-211)
+                g += n
         return out
 
     @torch.no_grad()

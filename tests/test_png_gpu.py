@@ -71,6 +71,29 @@ def test_png_batch_through_pipeline_vs_oracle(nets, ckpts):
         assert d.max() <= 1 and (d > 0).mean() < 0.02
 
 
+def test_png_batch_with_structure_prior_row(nets, ckpts):
+    """restore_strips(with_prior=True): next to ShowSR, the strip's structure images side by side — the array test_sr.py:208-211 builds from
+    ``prior_cha`` for the panel's last row — against the oracle's generator images; ShowSR itself is the same bytes with and without it"""
+    from marconet_amd.pipeline import MarconetPipeline
+    pipe = MarconetPipeline(*nets, precision="fp32")
+    strips = [lq_io.strip_from_png(os.path.join(cases_png.PNG_DIR, f)) for f in cases_png.SR_STRIPS.values()]
+    plain = pipe.restore_strips(strips)
+    outs = pipe.restore_strips(strips, with_prior=True)
+    for s, o, q in zip(strips, outs, plain):
+        show_sr, prior128 = o
+        assert np.array_equal(show_sr, q)
+        n = int(s["labels"].shape[0])
+        r = O.end_to_end(ckpts[0], ckpts[1], ckpts[2], s["lq"], [s["labels"]], s["locs"])
+        pc = (r["prior_images"][0] * 0.5 + 0.5).permute(0, 2, 3, 1).numpy()          # test_sr.py:208
+        ref = pc[0]
+        for i in range(1, len(pc)):                                                  # :209-211
+            ref = np.hstack((ref, pc[i]))
+        assert prior128.shape == ref.shape == (128, 128 * n, 3) and prior128.dtype == np.float32
+        err = float(np.abs(prior128 - ref).max())
+        print("prior row, %d glyphs: %.3e" % (n, err))
+        assert err <= 5e-4                                                           # (x*0.5+0.5 halves the 1e-3 bar of the image)
+
+
 def test_w_strips_clear_labels_and_interpolation(nets, golden_png):
     """test_w.py:59-108 on Testsets/TestW/w1.png / w2.png"""
     from marconet_amd.pipeline import clear_labels_batch, w_interpolation
