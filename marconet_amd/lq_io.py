@@ -6,6 +6,8 @@ what test_sr.py / test_w.py do to a PNG before ``modelEncoder(LQ)`` and to the b
     text → class indices through the 6735-character alphabet (−1 for an unknown character)                test_sr.py:24-35
     strip file name ``<anything>_<text>.png`` → the manual label                                          test_sr.py:156-158
 
+    the saved panel: preview | preview with box marks | SR | structure priors, stacked                   test_sr.py:203-232
+
 Pure host code (numpy / PIL): nothing here touches the GPU.  The YOLO + OCR front-end that produces boxes and text in the
 reference (utils/yolo_ocr_xloc.py) is outside the path (SURVEY.md §8f NEXT-4); ``evenly_spaced_boxes`` stands in for it where
 a harness needs boxes (plumbing config 1).
@@ -111,6 +113,72 @@ def lq_from_image(img):
     return t.unsqueeze(0), int(lq.shape[1]), show_w
 
 
+# ------------------------------------------------------------------------------------------------ the saved panel (test_sr.py:203-232)
+def show_lq(img):
+    """test_sr.py:99: ``ShowLQ`` — the strip at height 128 (uint8 RGB [128, show_w, 3]), the panel's first row and the crop width of the SR row"""
+    img = np.asarray(img)
+    return resize_cubic(img, 128 / img.shape[0], 128 / img.shape[0])
+
+
+def resize_linear(img, dst_w, dst_h):
+    """``cv2.resize(img, (dst_w, dst_h))`` (INTER_LINEAR, the default) for a float32 HxWxC image — test_sr.py:212 squeezes the row of
+    structure images to the preview's size with it.  OpenCV's float path: sample position (d + 0.5)·(src/dst) − 0.5, two taps per
+    axis, positions outside the image clamped to the border pixel, no antialiasing when shrinking, float32 arithmetic (horizontal
+    pass first).  UNPINNED against cv2 (not installable here), like ``resize_cubic``; it only shapes the visualisation row."""
+    img = np.asarray(img, dtype=np.float32)
+    h, w, _ = img.shape
+
+    def taps(n_dst, n_src):
+        f = (np.arange(n_dst, dtype=np.float64) + 0.5) * (n_src / n_dst) - 0.5
+        i0 = np.floor(f).astype(np.int64)
+        t = (f - i0).astype(np.float32)
+        t[i0 < 0] = 0.0
+        i0 = np.maximum(i0, 0)
+        t[i0 >= n_src - 1] = 0.0
+        i0 = np.minimum(i0, n_src - 1)
+        return i0, np.minimum(i0 + 1, n_src - 1), t
+
+    x0, x1, tx = taps(int(dst_w), w)
+    y0, y1, ty = taps(int(dst_h), h)
+    hor = img[:, x0, :] * (np.float32(1) - tx)[None, :, None] + img[:, x1, :] * tx[None, :, None]
+    return hor[y0] * (np.float32(1) - ty)[:, None, None] + hor[y1] * ty[:, None, None]
+
+
+def draw_locs(show, locs, n, img_max_width=16 * 128):
+    """test_sr.py:214-231: ``ShowLocs`` — a copy of the preview with, per character, a 4-px red mark at its left edge in the upper half
+    and a 2-px blue mark at its right edge in the lower half (RGB order; edges = int(centre·2048) ∓ int(half-width·2048), the two
+    products truncated separately as the script does).  ``locs``: the strip's ``preds_locs`` row [≥ 2n]."""
+    out = np.array(show, copy=True)
+    loc = np.asarray(locs, dtype=np.float32).reshape(-1)
+    pad, padr = 2, 1
+    for c in range(int(n)):
+        centre, width = int(float(loc[2 * c]) * img_max_width), int(float(loc[2 * c + 1]) * img_max_width)
+        x, y = centre - width, centre + width
+        a, b = max(0, x - pad), min(x + pad, img_max_width)
+        r, t = max(0, y - padr), min(y + padr, img_max_width)
+        out[:64, a:b, 0], out[:64, a:b, 1], out[:64, a:b, 2] = 255, 0, 0
+        out[64:, r:t, 0], out[64:, r:t, 1], out[64:, r:t, 2] = 0, 0, 255
+    return out
+
+
+def panel(image, locs, n, show_sr, prior128):
+    """test_sr.py:207-232: the array the script hands to ``cv2.imwrite`` — float [4·128, show_w, 3] in cv2's BGR order: the preview, the
+    preview with the box marks (both flipped RGB→BGR), ``ShowSR`` (already BGR, cropped to the preview's width), and the row of
+    structure images resized to the preview's size ×255 (NOT flipped: the script stacks that RGB array as it is, :212,232).
+    ``image``: the strip as loaded (uint8 RGB); ``show_sr`` / ``prior128``: ``MarconetPipeline.restore_strips(with_prior=True)``."""
+    show = show_lq(image)
+    prior = resize_linear(prior128, show.shape[1], show.shape[0]) * 255
+    return np.vstack((show[:, :, ::-1], draw_locs(show, locs, n)[:, :, ::-1], np.asarray(show_sr)[:, :show.shape[1], :], prior))
+
+
+def save_panel(path, bgr):
+    """``cv2.imwrite(path, bgr)`` for that array: saturate to uint8 with round-half-to-even (cv2's ``saturate_cast<uchar>``), BGR on
+    the way in → RGB file"""
+    from PIL import Image
+    u8 = np.clip(np.rint(np.asarray(bgr, dtype=np.float64)), 0, 255).astype(np.uint8)
+    Image.fromarray(np.ascontiguousarray(u8[:, :, ::-1])).save(path)
+
+
 def load_png(path):
     """uint8 RGB HxWx3 (the array get_yolo_ocr_xloc hands to the script, utils/yolo_ocr_xloc.py:37,103)"""
     from PIL import Image
@@ -148,4 +216,4 @@ def strip_from_png(path, text=None, boxes=None):
     boxes = evenly_spaced_boxes(len(text), w, h) if boxes is None else boxes
     lq, lq_w, show_w = lq_from_image(img)
     labels = torch.tensor(labels_from_text(text), dtype=torch.float32).type(torch.LongTensor).unsqueeze(1)   # test_sr.py:179
-    return dict(lq=lq, labels=labels, locs=locs_from_boxes(boxes, h), text=text, content_w=lq_w, show_w=show_w)
+    return dict(lq=lq, labels=labels, locs=locs_from_boxes(boxes, h), text=text, content_w=lq_w, show_w=show_w, image=img)

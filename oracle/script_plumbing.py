@@ -8,6 +8,7 @@ marconet_amd/lq_io.py can be checked against an independent statement:
     resize → canvas → ToTensor → Normalize            /root/reference/test_sr.py:98-115
     preds_locs from the detector's boxes              /root/reference/test_sr.py:121-135
     output post-processing                            /root/reference/test_sr.py:198-201
+    the saved panel (box marks, prior row, stacking)  /root/reference/test_sr.py:207-232
 
 ``cv2.resize(..., INTER_CUBIC)`` is third-party arithmetic that is absent here (cv2 is not installed, un-pinned in
 requirements.txt): it is restated from OpenCV's published 8-bit algorithm (4-tap cubic, A = −0.75, 11-bit fixed-point taps,
@@ -115,3 +116,65 @@ def postprocess(sr):
 def to_u8(img):
     """cv2.imwrite's float → uint8 conversion: saturate_cast<uchar> = round half to even"""
     return np.clip(np.rint(img), 0, 255).astype(np.uint8)
+
+
+def prior_row(prior_cha):
+    """test_sr.py:208-211: the generator's images [n,3,128,128] → one float array [128, 128·n, 3], side by side"""
+    pc = (prior_cha * 0.5 + 0.5).permute(0, 2, 3, 1).cpu().numpy()
+    row = pc[0]
+    for i in range(1, len(pc)):
+        row = np.hstack((row, pc[i]))
+    return row
+
+
+def cv2_resize_linear_f32(img, dst_w, dst_h):
+    """cv2.resize(img, (dst_w, dst_h)) with the default INTER_LINEAR on a float32 image (test_sr.py:212), restated from OpenCV's
+    published float algorithm as two dense interpolation matrices (rows: output positions; two non-zero weights each; sample position
+    (d + 0.5)·scale − 0.5, clamped to the border) — UNPINNED against cv2 like the cubic resampler above."""
+    img = np.asarray(img, dtype=np.float32)
+    h, w, c = img.shape
+
+    def matrix(n_dst, n_src):
+        m = np.zeros((n_dst, n_src), dtype=np.float32)
+        scale = n_src / n_dst
+        for d in range(n_dst):
+            f = (d + 0.5) * scale - 0.5
+            i = math.floor(f)
+            t = f - i
+            if i < 0:
+                i, t = 0, 0.0
+            if i >= n_src - 1:
+                i, t = n_src - 1, 0.0
+            m[d, i] += np.float32(1.0) - np.float32(t)
+            if t:
+                m[d, i + 1] += np.float32(t)
+        return m
+
+    mx, my = matrix(dst_w, w), matrix(dst_h, h)
+    hor = np.einsum("dw,hwc->hdc", mx, img)
+    return np.einsum("eh,hdc->edc", my, hor)
+
+
+def show_locs(show, preds_locs, n_chars):
+    """test_sr.py:214-231, one column at a time: which columns of the upper half turn red (the 4 px around each character's left edge)
+    and which of the lower half turn blue (the 2 px around its right edge); RGB order, as ShowLQ is"""
+    out = show.copy()
+    width_limit = 16 * 128
+    cols = out.shape[1]
+    for c in range(n_chars):
+        centre = int(preds_locs[0][2 * c].item() * width_limit)
+        half = int(preds_locs[0][2 * c + 1].item() * width_limit)
+        left, right = centre - half, centre + half
+        red = range(cols)[max(0, left - 2):min(left + 2, width_limit)]
+        blue = range(cols)[max(0, right - 1):min(right + 1, width_limit)]
+        for col in red:
+            out[:64, col] = (255, 0, 0)
+        for col in blue:
+            out[64:, col] = (0, 0, 255)
+    return out
+
+
+def panel(show, preds_locs, n_chars, show_sr, prior_cha):
+    """test_sr.py:207-232: the stacked array handed to cv2.imwrite (BGR): preview, box marks, SR row, prior row"""
+    prior = cv2_resize_linear_f32(prior_row(prior_cha), show.shape[1], show.shape[0]) * 255
+    return np.vstack((show[:, :, ::-1], show_locs(show, preds_locs, n_chars)[:, :, ::-1], show_sr, prior))

@@ -79,6 +79,46 @@ def test_resize_identity_and_constant():
     assert (lq_io.resize_cubic(flat, 32 / 9, 32 / 9) == 137).all()      # fixed-point taps sum to exactly 2048
 
 
+def test_panel_helpers_match_script_statement(tmp_path):
+    """test_sr.py:207-232 (the saved visualisation): box marks, the structure-prior row squeezed to the preview's size, the stacking and
+    the uint8 file — lq_io's vectorised forms against the scalar restatement in oracle/script_plumbing.py, on a reference strip with
+    random "SR" and "prior" rows (the networks are not involved) and on marks that run over both edges of the preview"""
+    rng = np.random.default_rng(5)
+    fname = sorted(cases_png.SR_STRIPS.values())[0]
+    s = lq_io.strip_from_png(os.path.join(cases_png.PNG_DIR, fname))
+    n = int(s["labels"].shape[0])
+    show = lq_io.show_lq(s["image"])
+    assert show.shape == (128, s["show_w"], 3) and show.dtype == np.uint8
+    # marks: the strip's own boxes, then boxes whose edges leave the preview on the left (negative slice ends: the script's own quirk) and right
+    for locs in (s["locs"], torch.tensor([[0.0004, 0.002, 0.5, 0.01, 0.9995, 0.003]]), torch.tensor([[0.0, 0.004, 1.2, 0.05]])):
+        k = locs.shape[1] // 2
+        assert np.array_equal(lq_io.draw_locs(show, locs[0], k), SP.show_locs(show, locs, k))
+    marked = lq_io.draw_locs(show, s["locs"][0], n)
+    assert (marked != show).any() and (marked[:64, :, 0] == 255).any() and (marked[64:, :, 2] == 255).any()
+    # bilinear squeeze of the prior row: shrink (the script's case), enlarge, identity
+    prior_cha = torch.from_numpy(rng.uniform(-1, 1, (n, 3, 128, 128)).astype(np.float32))
+    row = SP.prior_row(prior_cha)
+    assert row.shape == (128, 128 * n, 3)
+    for dw, dh in ((s["show_w"], 128), (128 * n + 37, 150), (128 * n, 128), (5, 3)):
+        a, b = lq_io.resize_linear(row, dw, dh), SP.cv2_resize_linear_f32(row, dw, dh)
+        assert a.shape == b.shape == (dh, dw, 3) and a.dtype == np.float32
+        assert float(np.abs(a - b).max()) <= 2e-6
+    assert np.array_equal(lq_io.resize_linear(row, 128 * n, 128), row)
+    const = lq_io.resize_linear(np.full((7, 9, 3), 0.25, np.float32), 31, 17)
+    assert float(np.abs(const - 0.25).max()) <= 1e-7
+    # the stacked panel and the file
+    show_sr = rng.uniform(0, 255, (128, 2048, 3)).astype(np.float32)
+    pa = lq_io.panel(s["image"], s["locs"][0], n, show_sr, row)
+    pb = SP.panel(show, s["locs"], n, show_sr[:, :show.shape[1], :], prior_cha)
+    assert pa.shape == pb.shape == (4 * 128, s["show_w"], 3)
+    assert float(np.abs(pa - pb).max()) <= 1e-3                      # (rows 1-3 identical; the prior row x255 carries the 2e-6 above)
+    out = os.path.join(str(tmp_path), "panel.png")
+    lq_io.save_panel(out, pa)
+    back = lq_io.load_png(out)                                        # RGB
+    assert np.array_equal(back[:, :, ::-1], SP.to_u8(pa))
+    assert np.array_equal(back[:128], show)                           # the preview row survives the BGR round trip
+
+
 @pytest.mark.parametrize("tag", list(cases_png.SR_STRIPS))
 def test_png_through_cpu_path_vs_golden(tag, ckpts, golden_png):
     """configs[0]: one PNG through the test_sr.py path on PyTorch-CPU — product plumbing + CPU oracle vs the real reference"""

@@ -94,6 +94,37 @@ def test_png_batch_with_structure_prior_row(nets, ckpts):
         assert err <= 5e-4                                                           # (x*0.5+0.5 halves the 1e-3 bar of the image)
 
 
+def test_example_script_writes_the_script_panels(tmp_path):
+    """examples/restore_strips.py -m on the reference's own strips: one panel PNG per strip under the script's file name (test_sr.py:232),
+    4 x 128 rows — preview, box marks, the SR row MarconetPipeline.restore_strips gives in this process, the structure-prior row"""
+    import subprocess
+    import sys
+    from marconet_amd import checkpoints
+    from marconet_amd.pipeline import MarconetPipeline
+    out = str(tmp_path / "panels")
+    env = dict(os.environ)
+    env.pop("MARCONET_CKPT_DIR", None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "examples", "restore_strips.py"), "-i", cases_png.PNG_DIR, "-o", out, "-m", "--precision", "fp32"],
+                       capture_output=True, text=True, env=env, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    sde, sdg, sds, _ = checkpoints.load_state_dicts("")
+    pipe = MarconetPipeline(*checkpoints.build_networks(sde, sdg, sds, DEV), precision="fp32")
+    for fname in cases_png.SR_STRIPS.values():
+        base = os.path.splitext(fname)[0]
+        s = lq_io.strip_from_png(os.path.join(cases_png.PNG_DIR, fname))
+        path = os.path.join(out, "%s_%s.png" % (base, s["text"]))
+        assert os.path.isfile(path), (sorted(os.listdir(out)), r.stdout[-1500:])
+        img = lq_io.load_png(path)                                               # RGB; the script's array is BGR
+        assert img.shape == (4 * 128, s["show_w"], 3)
+        show = lq_io.show_lq(s["image"])
+        assert np.array_equal(img[:128], show)
+        assert np.array_equal(img[128:256], lq_io.draw_locs(show, s["locs"][0], len(s["text"])))
+        show_sr, prior128 = pipe.restore_strips([s], with_prior=True)[0]
+        assert np.array_equal(img[256:384][:, :, ::-1], show_sr)
+        want = SP.to_u8(lq_io.resize_linear(prior128, show.shape[1], 128) * 255)
+        assert np.array_equal(img[384:][:, :, ::-1], want)
+
+
 def test_w_strips_clear_labels_and_interpolation(nets, golden_png):
     """test_w.py:59-108 on Testsets/TestW/w1.png / w2.png"""
     from marconet_amd.pipeline import clear_labels_batch, w_interpolation
