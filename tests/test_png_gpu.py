@@ -125,6 +125,38 @@ def test_example_script_writes_the_script_panels(tmp_path):
         assert np.array_equal(img[384:][:, :, ::-1], want)
 
 
+def test_example_w_script_writes_the_interpolation_frames(tmp_path):
+    """examples/interpolate_w.py on Testsets/TestW: the script's eleven PNGs + w.gif (test_w.py:100-113); the middle frame against the same
+    computation in this process (one generator call for all steps)"""
+    import importlib.util
+    import subprocess
+    import sys
+    from PIL import Image
+    from marconet_amd import checkpoints
+    out = str(tmp_path / "w")
+    env = dict(os.environ)
+    env.pop("MARCONET_CKPT_DIR", None)
+    w1, w2 = (os.path.join(cases_png.PNG_DIR, f) for f in cases_png.W_STRIPS)
+    script = os.path.join(ROOT, "examples", "interpolate_w.py")
+    r = subprocess.run([sys.executable, script, "-w1", w1, "-w2", w2, "-o", out], capture_output=True, text=True, env=env, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    names = sorted(os.listdir(out))
+    assert names == sorted(["w_%.2f.png" % (i / 10) for i in range(11)] + ["w.gif"]), names
+    spec = importlib.util.spec_from_file_location("interpolate_w_example", script)
+    ex = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(ex)
+    sde, sdg, sds, _ = checkpoints.load_state_dicts("")
+    enc, gan, _ = checkpoints.build_networks(sde, sdg, sds, DEV)
+    enc.set_precision("fp32")
+    gan.set_precision("fp32")
+    rows = ex.frames(enc, gan, w1, w2, DEV)
+    assert len(rows) == 11 and rows[0].shape[0] == 128 and rows[0].shape[1] % 128 == 0
+    mid = lq_io.load_png(os.path.join(out, "w_0.50.png"))
+    assert np.array_equal(mid[:, :, ::-1], SP.to_u8(rows[5] * 255.0))            # the RGB row written as if BGR (test_w.py:111)
+    with Image.open(os.path.join(out, "w.gif")) as g:
+        assert g.n_frames == 11 and g.size == (rows[0].shape[1], 128)
+
+
 def test_w_strips_clear_labels_and_interpolation(nets, golden_png):
     """test_w.py:59-108 on Testsets/TestW/w1.png / w2.png"""
     from marconet_amd.pipeline import clear_labels_batch, w_interpolation
