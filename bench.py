@@ -109,6 +109,9 @@ def parse():
     ap.add_argument("--no-regimes", action="store_true", help="skip the parity sample on the trained-like weight regime")
     ap.add_argument("--cpu-threads", type=int, default=32, help="cap on host threads for the CPU baseline")
     ap.add_argument("--no-gather", action="store_true")
+    ap.add_argument("--dry", action="store_true", help="plumbing check without a GPU: gloo process group, a stand-in forward (a deterministic function of each image "
+                                                       "alone) through the same launch / shard / overlapped all-gather / barrier + max-over-ranks timing / JSON code; "
+                                                       "the line says \"dry\": true and carries no throughput claim (tests/test_bench_launch.py)")
     ap.add_argument("--gather-format", default="u8", choices=["u8", "f32"], help="N>1: what is all-gathered — the post-processed uint8 BGR image (0.75 MiB/img) or the fp32 NCHW tensor (3 MiB/img)")
     return ap.parse_args()
 
@@ -237,14 +240,84 @@ def flat_roofline(r):
             "all_conv_TFLOPs": r["all_conv_kernels"]["achieved"], "hbm_tail_ms": r["hbm_tail"]["ms_per_step"], "hbm_tail_GB_per_s": r["hbm_tail"]["GB_per_s"]}
 
 
+def self_launch(n):
+    """`python bench.py --gpus N` from a plain shell (no WORLD_SIZE in the environment): re-execute under torch.distributed.run with one rank per GPU on
+    127.0.0.1 — the command line the driver's contract spells out — and hand its exit status back.  Rank 0 of that job prints the one JSON line."""
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")          # dmabuf IPC only on this host driver (RCCL across processes)
+    env.setdefault("OMP_NUM_THREADS", str(max(1, host_threads(32) // n)))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
+
+
+def dry_main(a, world, rank):
+    """--dry: everything of the N-rank bench that is not the HIP forward — process group, per-rank batch, overlapped all-gather of the uint8 outputs,
+    barrier + max-over-ranks timing, per-rank rates, ONE JSON line from rank 0 — on CPU tensors over gloo with a stand-in forward"""
+    import torch.distributed as dist
+    from marconet_amd.pipeline import OverlappedGather
+    dev = torch.device("cpu")
+    if world > 1 or a.force_gather:
+        if world == 1:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29534")
+            os.environ.setdefault("RANK", "0"); os.environ.setdefault("WORLD_SIZE", "1")
+        dist.init_process_group("gloo")
+    B = min(a.batch, 8)
+    gather = OverlappedGather() if (world > 1 or a.force_gather) and not a.no_gather else None
+
+    def fence():
+        if gather is not None:
+            gather.flush()
+        if world > 1:
+            dist.barrier()
+
+    def stand_in(i):                 # "SR output" of global image i: a function of i alone (uint8 BGR, a 1/64 thumbnail of [128,2048,3])
+        g = torch.Generator().manual_seed(5000 + i)
+        return torch.randint(0, 256, (16, 256, 3), generator=g, dtype=torch.uint8)
+
+    def step():
+        y = torch.stack([stand_in(rank * B + b) for b in range(B)])
+        if gather is not None:
+            gather.submit(y)
+        return y
+    for _ in range(a.warmup):
+        step()
+    dt, per_rank_dt, _ = timed(step, fence, a.steps, world, dev)
+    ok = None
+    if gather is not None:           # the collective's result: every rank's shard at its place
+        gather.submit(step())
+        full = gather.flush()
+        ok = bool(torch.equal(full, torch.stack([stand_in(i) for i in range(world * B)])))
+    if rank == 0:
+        out = {"metric": "SR images/sec (32x512 LR -> 128x2048 SR)", "value": round(world * B * a.steps / dt, 3), "unit": "images/s", "n_gpus": world,
+               "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(dt / a.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+               "vs_baseline": None, "dtype": "u8", "data": "DRY RUN: stand-in forward on CPU, no throughput claim", "dry": True,
+               "config": {"workload": "dry run: %d stand-in images per rank, gloo" % B, "per_gpu_batch": B, "global_batch": world * B, "parallelism": "dp%d" % world,
+                          "collective": "gloo world of %d: all_gather(uint8), asynchronous, overlapped with the next step" % world if gather is not None else "none"},
+               "roofline": None, "cpu_baseline": None,
+               "ranks": {"world_size": dist.get_world_size() if dist.is_initialized() else 1, "backend": dist.get_backend() if dist.is_initialized() else None,
+                         "per_rank_images_per_s": [round(B * a.steps / t_, 2) for t_ in per_rank_dt], "gathered_equals_single_process": ok}}
+        print(json.dumps(out), flush=True)
+    if dist.is_initialized():
+        dist.barrier()
+        dist.destroy_process_group()
+
+
 def main():
     a = parse()
+    if "WORLD_SIZE" not in os.environ and a.gpus > 1:
+        raise SystemExit(self_launch(a.gpus))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != a.gpus:
-        if world == 1 and a.gpus > 1:
-            raise SystemExit("--gpus %d needs torch.distributed.run with --nproc-per-node %d" % (a.gpus, a.gpus))
+    if a.dry:
+        return dry_main(a, world, rank)
     import torch.distributed as dist
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)

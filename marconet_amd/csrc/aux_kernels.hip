@@ -677,12 +677,11 @@ __global__ void __launch_bounds__(256) glyph_scatter_kernel(const T* __restrict_
     const T* fp = feat + (size_t)b * S * row + (size_t)id * N;
     T* op = out + (size_t)b * S * row + (size_t)id * N;
     if (owner < 0) {
-#pragma unroll 4
         for (int y = 0; y < S; ++y) straw<T>(op + (size_t)y * row, ldraw<T>(fp + (size_t)y * row));
         return;
     }
     const size_t go = ((size_t)owner * S * S + ox) * C + (size_t)ch * N;     // + y*S*C per row
-#pragma unroll 4
+    // (no unroll request: hipcc cannot honour one on this runtime-bounded loop behind the owner look-up — it warned and left the loop rolled; same code without it)
     for (int y = 0; y < S; ++y) {
         float f[N], sc[N], sh[N], o[N];
         unpackr<T>(ldraw<T>(fp + (size_t)y * row), f);

@@ -298,11 +298,46 @@ def gn_partial_buffer(n, h, w, c, device):
     return torch.empty((n * h * w // 32, c // 32, 2), dtype=torch.float32, device=device)
 
 
+_PLAN_CACHE = {}
+
+
+def conv_plan(x0, cout, kh=1, kw=1, stride=(1, 1), pad=(0, 0), x1=None, algo=0):
+    """mnet_conv2d_plan for the launch geometry of ``conv2d(x0, …, x1=…)``: the kernel ``algo`` resolves to (_lib.ALGO_REG_STAGED, ALGO_SKINNY,
+    ALGO_DMA_CFG0 + id, ALGO_STRIP_CFG0 + id, ALGO_DMA_CFG16 + id), or a negative MNET_E_* when the planner refuses it.  Nothing is launched; the
+    answer depends on geometry and storage type only and is cached per (dtype, shape, filter, algo) — the callers that choose between two forms
+    of a layer ask this instead of launching and parsing an error message."""
+    n, h, w, c0 = x0.shape
+    c1 = 0 if x1 is None else x1.shape[3]
+    key = (_dt(x0), n, h, w, c0, c1, cout, kh, kw, tuple(stride), tuple(pad), algo)
+    k = _PLAN_CACHE.get(key)
+    if k is None:
+        lib = _lib.load()
+        d = ConvDesc()
+        d.dtype = key[0]
+        d.x0, d.c0 = x0.data_ptr(), c0
+        d.x1, d.c1 = (None if x1 is None else x1.data_ptr()), c1
+        d.n, d.h, d.w = n, h, w
+        d.wgt = d.y = x0.data_ptr()            # (the planner checks presence and alignment of the pointers, nothing behind them)
+        d.cout, d.kh, d.kw = cout, kh, kw
+        d.stride_h, d.stride_w, d.pad_h, d.pad_w = stride[0], stride[1], pad[0], pad[1]
+        d.ho, d.wo = (h + 2 * pad[0] - kh) // stride[0] + 1, (w + 2 * pad[1] - kw) // stride[1] + 1
+        k = _PLAN_CACHE[key] = int(lib.mnet_conv2d_plan(ctypes.byref(d), algo))
+    return k
+
+
+def plan_is_lds_dma(k):
+    """a planner answer that names one of the LDS-DMA tile configurations (not the strip kernel, not the register-staged / skinny ones)"""
+    return _lib.ALGO_DMA_CFG0 <= k < _lib.ALGO_STRIP_CFG0 or k >= _lib.ALGO_DMA_CFG16
+
+
 def can_emit_gn_partial(x0, x1, cout, stride, ho, wo):
-    """the launches whose epilogue can write GroupNorm partial sums (mnet_conv_desc.gn_partial): fp16+8 storage on the LDS-DMA / strip kernels"""
+    """the launches whose epilogue can write GroupNorm partial sums (mnet_conv_desc.gn_partial): fp16+8 storage, and a launch the planner gives to the
+    LDS-DMA / strip kernels (3x3 'same' geometry of this network's GroupNorm producers)"""
     c = x0.shape[3] + (0 if x1 is None else x1.shape[3])
-    return (x0.dtype == MX_DTYPE and tuple(stride) == (1, 1) and cout >= 64 and cout % 32 == 0 and c % 32 == 0 and x0.shape[3] % 32 == 0
-            and (ho * wo) % 32 == 0 and not _NO_EPILOGUE_GN)
+    if not (x0.dtype == MX_DTYPE and tuple(stride) == (1, 1) and cout >= 64 and cout % 32 == 0 and c % 32 == 0 and x0.shape[3] % 32 == 0
+            and (ho * wo) % 32 == 0 and not _NO_EPILOGUE_GN):
+        return False
+    return conv_plan(x0, cout, 3, 3, stride, (1, 1), x1=x1) >= _lib.ALGO_DMA_CFG0
 
 
 def groupnorm_affine_from_partial(partial, n, h, w, c, gamma, beta, eps=1e-6, valid_w=None):

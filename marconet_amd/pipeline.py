@@ -356,12 +356,20 @@ class GraphedForward:
             # pipe — an eager forward_batch, another GraphedForward — and must not be read here)
             self._flag = pipe._finite
             self._checks = pipe._checks()
+            self._quiet_without_flag = pipe.precision == "fp32" and pipe.check_finite is None     # as captured
+
+    @property
+    def has_flag(self):
+        """True when this graph refreshes a finiteness flag on every replay (captured with the check on)"""
+        return self._flag is not None
 
     def raise_if_not_finite(self):
         """reads this graph's own flag (one device→host synchronisation) — for callers that replay with check=False and test later"""
         if self._flag is None:
-            raise RuntimeError("GraphedForward: this graph was captured with the finiteness check off (check_finite=False, or the fp32 mode): "
-                               "there is no flag to read — capture with MarconetPipeline(check_finite=True)")
+            if self._quiet_without_flag:
+                return       # fp32 has no half-range overflow to report: code shared with the half-range modes may call this unconditionally (ADVICE r5)
+            raise RuntimeError("GraphedForward: this graph was captured with the finiteness check off (check_finite=False): "
+                               "there is no flag to read — capture with MarconetPipeline(check_finite=True); `has_flag` tells")
         if any(self._flag.cpu().tolist()):
             raise FloatingPointError("marconet_amd: non-finite SR output in %s mode (activations beyond the fp16 range 65504?) — use "
                                      "precision='fp32' for these weights" % self.pipe.precision)

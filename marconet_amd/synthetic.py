@@ -303,10 +303,19 @@ def _resblock(sd, seed, key, cin, cout):
 def make_sr_state_dict(seed=1234, outliers=None, regime="tame"):
     """Keys of ``TSPSRNet`` (models/networks.py:328-409).  ``outliers``: see _apply_outliers; a ``*.weight_orig`` entry scales that output
     row of a spectral-normalised conv before its u / v are power-iterated."""
+    trained = _check_regime(regime)
+    try:        # the regime / outlier switches of the helpers below are module state: restored on EVERY exit (ADVICE r5: an exception used to leave them set)
+        _SR_TRAINED[0] = trained
+        _SN_ROW_GAIN.clear()
+        _SN_ROW_GAIN.update({k: v for k, v in (outliers or {}).items() if k.endswith(".weight_orig")})
+        return _make_sr_state_dict(seed, outliers)
+    finally:
+        _SN_ROW_GAIN.clear()
+        _SR_TRAINED[0] = False
+
+
+def _make_sr_state_dict(seed, outliers):
     sd = {}
-    _SR_TRAINED[0] = _check_regime(regime)
-    _SN_ROW_GAIN.clear()
-    _SN_ROW_GAIN.update({k: v for k, v in (outliers or {}).items() if k.endswith(".weight_orig")})
     D = 256
     _sn_conv(sd, seed, "conv_first_32.0", D // 4, 3)
     _sn_conv(sd, seed, "conv_first_16.0", D // 2, D // 4)
@@ -333,8 +342,6 @@ def make_sr_state_dict(seed=1234, outliers=None, regime="tame"):
     _sn_conv(sd, seed, "conv_32_to256.2", D, D)
     missing = [k for k in _SN_ROW_GAIN if k not in sd]
     _apply_outliers(sd, outliers, skip=tuple(_SN_ROW_GAIN))
-    _SN_ROW_GAIN.clear()
-    _SR_TRAINED[0] = False
     if missing:
         raise KeyError("outlier keys %s not in this state_dict" % missing)
     return sd

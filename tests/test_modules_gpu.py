@@ -744,6 +744,11 @@ def test_hip_graph_replay_equals_eager(nets, output, precision):
             assert got.dtype == want.dtype and torch.equal(got, want), seed
         with pytest.raises(ValueError):
             gf(lq, [labels[0], labels[2], labels[2]], locs)
+        # the documented latency pattern — replay with check=False, test when the output is consumed — in every mode (the fp32 mode
+        # captures no flag, overflow being impossible there, and must return quietly)
+        gf(lq, labels, locs, check=False)
+        gf.raise_if_not_finite()
+        assert gf.has_flag == (precision != "fp32")
     finally:
         pipe.set_precision("fp32")
 
