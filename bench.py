@@ -65,7 +65,7 @@ KNAME_X2 = {16: "conv_dma_kernel<256,256,4,4,2,32,mx>", 17: "conv_dma_kernel<256
             22: "conv_dma_kernel<256,256,2,4,2,32,mx>", 23: "conv_dma_kernel<128,512,2,4,2,32,mx>", 24: "conv_dma_kernel<128,512,1,8,2,32,mx>",
             26: "conv_dma_kernel<128,128,2,4,4,32,mx>", 27: "conv_dma_kernel<256,256,2,4,2,32,mx,pipe>", 28: "conv_dma_kernel<128,512,1,8,2,32,mx,pipe>",
             29: "conv_dma_kernel<64,512,1,8,2,32,mx,pipe>", 31: "conv_dma_kernel<256,256,2,4,2,32,mx,swp>", 25: "conv_dma_kernel<128,512,1,8,2,32,mx,swp>",
-            32: "conv_strip_kernel<256,256,2,4,mx>", 33: "conv_strip_kernel<64,512,1,8,mx>"}
+            32: "conv_strip_kernel<256,256,2,4,mx>", 33: "conv_strip_kernel<64,512,1,8,mx>", 64: "conv_dma_w4_kernel"}
 DTNAME = {0: "f32", 1: "f16", 2: "f16x3", 3: "f16x2"}
 MFMA_UNITS = {0: 1.0, 1: 1.0, 2: 3.0, 3: 2.0}      # fp16-MFMA-equivalent time units per algorithmic product
 

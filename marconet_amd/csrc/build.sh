@@ -11,7 +11,7 @@ if [ "${MNET_CLEAN:-0}" != "0" ]; then rm -f "$OUT"/*.o "$OUT"/*.o.tmp "$OUT"/*.
 HIPCC="${HIPCC:-/opt/rocm/bin/hipcc}"
 PIDS=()
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-function"
-SRCS="api conv_igemm conv_igemm_dma conv_dma_swp_gn conv_strip_dma conv_skinny aux_kernels vit_kernels pack_kernels"
+SRCS="api conv_igemm conv_igemm_dma conv_dma_swp_gn conv_dma_w4 conv_strip_dma conv_skinny aux_kernels vit_kernels pack_kernels"
 # per-source extra flags (conv_dma_swp_gn: see the note at its top)
 extra() { case "$1" in conv_dma_swp_gn) echo "-mllvm -greedy-reverse-local-assignment=1" ;; *) echo "" ;; esac; }
 HDRS="$HERE/common.h $HERE/conv_args.h $HERE/conv_dma_common.h $HERE/../../include/marconet_hip.h"

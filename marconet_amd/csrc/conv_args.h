@@ -29,6 +29,9 @@ bool conv_dma_eligible(const ConvArgs& a, int dtype);
 int conv_dma_pick(const ConvArgs& a);                           // tile configuration id AUTO would use
 int launch_conv_dma(const ConvArgs& a, hipStream_t st, int cfg);   // cfg < 0: conv_dma_pick
 
+// conv_dma_w4.hip (fp16+8 256x256 tile, one wave per SIMD, accumulators in the accumulator file: fp16+8 LDS-DMA id 16)
+int launch_conv_dma_w4(const ConvArgs& a, hipStream_t st);
+
 // conv_strip_dma.hip (3x3 / stride 1: one activation strip per filter row)
 int conv_strip_pick(const ConvArgs& a, int dtype, bool explicit_request);   // strip configuration id, or -1 when not eligible / not preferred
 int launch_conv_strip(const ConvArgs& a, hipStream_t st, int cfg);

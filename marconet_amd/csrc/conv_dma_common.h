@@ -89,9 +89,16 @@ __device__ __forceinline__ float* kernarg_gn_partial() {
 // GN: this instantiation can write the GroupNorm partial sums (ConvArgs::gn_partial).  The software-pipelined tiles are built without it: the extra
 // live values of that block moved hipcc's spill choice into their slab loop (two scratch accesses on the hot path, tools/isa_hot_scratch.py); launches
 // that ask for the sums take the lock-step form of the same tile (conv_dma_pick), which stays clean.
-template <int BC, int BP, int WC, int WP, int FC, int FP, int XL = 64, bool GN = true>
-__device__ __forceinline__ void dma_epilogue_mx(const ConvArgs& p, const f32x16 (&acc32)[FC / 2][FP / 2], int co0, int pix0, int wc, int wp, int lane,
-                                                unsigned char* xpose = nullptr) {
+// ACC: where the accumulator blocks are — `acc.get(fa, px, q)` = value q of block (weight fragment fa, pixel fragment px).  The 8 / 16-wave tiles hand over their VGPR
+// array (AccArray); the one-wave-per-SIMD tile (conv_dma_w4.hip) reads its blocks out of the accumulator file where they are consumed.
+template <int FA, int FB>
+struct AccArray {
+    const f32x16 (&r)[FA][FB];
+    __device__ __forceinline__ float get(int fa, int px, int q) const { return r[fa][px][q]; }
+};
+template <int BC, int BP, int WC, int WP, int FC, int FP, int XL = 64, bool GN = true, typename ACC>
+__device__ __forceinline__ void dma_epilogue_mx_acc(const ConvArgs& p, const ACC& acc32, int co0, int pix0, int wc, int wp, int lane,
+                                                    unsigned char* xpose = nullptr) {
     static_assert(XL == 64 || XL == 16, "scratch of 4 KiB or 1 KiB per wave");
     constexpr int NPX = FP / 2, NB = FC / 4;
     const int h = lane >> 5;
@@ -111,7 +118,7 @@ __device__ __forceinline__ void dma_epilogue_mx(const ConvArgs& p, const f32x16 
             const int co = cob + h * 32;                                    // first channel of this lane's block
             float v[32];
 #pragma unroll
-            for (int q = 0; q < 16; ++q) { v[q] = acc32[2 * b][px][q] * MNET_SPLIT_WSCALE_INV; v[16 + q] = acc32[2 * b + 1][px][q] * MNET_SPLIT_WSCALE_INV; }
+            for (int q = 0; q < 16; ++q) { v[q] = acc32.get(2 * b, px, q) * MNET_SPLIT_WSCALE_INV; v[16 + q] = acc32.get(2 * b + 1, px, q) * MNET_SPLIT_WSCALE_INV; }
             if (!xpose && co >= p.cout) continue;
             // (through the LDS every lane takes part: a lane whose block lies beyond cout works on the last block's parameters instead — loads in
             //  range, no divergent region around 32 live values — and nobody stores its result)
@@ -264,6 +271,12 @@ __device__ __forceinline__ void dma_epilogue_mx(const ConvArgs& p, const f32x16 
             gn_finish();
         }
     }
+}
+
+template <int BC, int BP, int WC, int WP, int FC, int FP, int XL = 64, bool GN = true>
+__device__ __forceinline__ void dma_epilogue_mx(const ConvArgs& p, const f32x16 (&acc32)[FC / 2][FP / 2], int co0, int pix0, int wc, int wp, int lane,
+                                                unsigned char* xpose = nullptr) {
+    dma_epilogue_mx_acc<BC, BP, WC, WP, FC, FP, XL, GN>(p, AccArray<FC / 2, FP / 2>{acc32}, co0, pix0, wc, wp, lane, xpose);
 }
 
 // Epilogue of one (cout tile co0, pixel tile pix0): identical math to conv_igemm.hip.  Every lane owns NG groups of 8

@@ -939,6 +939,7 @@ static int launch_dma_id(int id, const ConvArgs& a, hipStream_t st) {
             case 13: return launch_dma_cfg<64, 512, 1, 8, 2, 32, 0, true, true, true, true>(a, st);           // id 5, same
             case 15: return launch_dma_cfg<256, 256, 2, 4, 2, 32, 0, true, false, false, true, true>(a, st);       // id 6 with the slab loop software-pipelined across the barrier (SWP)
             case 9: return launch_dma_cfg<128, 512, 1, 8, 2, 32, 0, true, false, false, true, true>(a, st);        // id 8, same
+            case 16: return launch_conv_dma_w4(a, st);     // round 6: the 256x256 tile with ONE wave per SIMD (4 waves x 128x128, accumulators in a[0:255]): conv_dma_w4.hip
             case 14: {                  // DIAGNOSTIC (wrong results): id 11 with per-phase cycle sums written over the output (tools/slab_phases.py)
                 static const bool allow = [] { const char* e = getenv("MNET_ALLOW_DIAGNOSTIC_KERNELS"); return e && atoi(e) != 0; }();
                 if (!allow) return mnet_fail(MNET_E_ARG, "conv: fp16+8 LDS-DMA id 14 is a diagnostic build with wrong results (set MNET_ALLOW_DIAGNOSTIC_KERNELS=1 to use it)");
@@ -1053,7 +1054,7 @@ int launch_conv_dma(const ConvArgs& a, hipStream_t st, int cfg) {
     int id = cfg >= 0 ? cfg : conv_dma_pick(a);
     // launches that write GroupNorm partial sums: the software-pipelined tiles of THIS translation unit are built without that block (dma_epilogue_mx<..., GN = false>);
     // id 15 has a build with it in conv_dma_swp_gn.hip, id 9 hands over to its lock-step form 8 (the same tile shape, the same MFMA sequence, the same bytes)
-    if (a.gn_partial && a.split == 2) {
+    if (a.gn_partial && a.split == 2) {       // (id 16, the one-wave-per-SIMD tile, writes the sums itself)
         if (id == 15) return launch_dma_swp_gn(a, st);
         if (id == 9) id = 8;
     }

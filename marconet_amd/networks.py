@@ -370,7 +370,7 @@ def _as_rows32(x):
     m = flat.shape[1]
     mp = (m + 31) // 32 * 32
     if mp != m:
-        flat = torch.nn.functional.pad(flat, (0, mp - m))
+        flat = torch.cat([flat, flat.new_zeros((flat.shape[0], mp - m))], dim=1)
     return flat.reshape(b * c, 1, mp // 32, 32), m, mp
 
 
@@ -380,7 +380,7 @@ def swish(x):
     m = v.shape[1]
     mp = (m + 31) // 32 * 32
     if mp != m:
-        v = torch.nn.functional.pad(v, (0, mp - m))
+        v = torch.cat([v, v.new_zeros((1, mp - m))], dim=1)
     one = torch.ones((1, 32), dtype=torch.float32, device=x.device)
     y = ops.affine_act(v.reshape(1, 1, mp // 32, 32), one, None, swish=True)
     return y.reshape(-1)[:m].reshape(x.shape)

@@ -92,6 +92,12 @@ def _emulate(x, w, **kw):
     return y / M.WSCALE
 
 
+def _tile(id_):
+    """algo value that pins LDS-DMA tile configuration ``id_`` (ids 0-15: MNET_CONV_ALGO_DMA_CFG0 + id; 16...: MNET_CONV_ALGO_DMA_CFG16 + id - 16)"""
+    from marconet_amd import _lib
+    return _lib.ALGO_DMA_CFG0 + id_ if id_ < 16 else _lib.ALGO_DMA_CFG16 + (id_ - 16)
+
+
 def _check(name, got, ref, tol):
     scale = max(ref.abs().max().item(), 1e-6)
     err = (got.double() - ref.double()).abs().max().item()
@@ -196,7 +202,7 @@ def test_conv_plain(case):
         _check("fp16+8 conv (register-staged) %s" % (case,), got, F.conv2d(x.double(), _wdec(wt).double(), stride=stride, padding=pad), 2e-5)
 
 
-@pytest.mark.parametrize("id_", [0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 15])
+@pytest.mark.parametrize("id_", [0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 15, 16])
 def test_every_lds_dma_tile_configuration(id_):
     """each fp16+8 instantiation of the LDS-DMA kernel, pinned explicitly, with the full epilogue"""
     ops = _ops()
@@ -214,7 +220,7 @@ def test_every_lds_dma_tile_configuration(id_):
         r = conv * osc[:, :, None, None] + bias[None, :, None, None] + res
         return F.leaky_relu(r, 0.2) * 2 ** 0.5 * psc[:, :, None, None]
     y = ops.conv2d(_to_mx(x), _pack_w(wt), cout, 3, 3, (1, 1), (1, 1), out_scale=osc.to(DEV), bias=bias.to(DEV),
-                   residual=_to_mx(res), act=3, post_scale=psc.to(DEV), valid_w=vw.to(DEV), algo=16 + id_)
+                   residual=_to_mx(res), act=3, post_scale=psc.to(DEV), valid_w=vw.to(DEV), algo=_tile(id_))
     torch.cuda.synchronize()
     got = _from_mx(y)
     _check("fp16+8 LDS-DMA id %d vs emulation" % id_, got, full(_emulate(xm, wt, padding=1)), 2e-5)
@@ -227,7 +233,7 @@ def test_lds_dma_tiles_agree_bit_for_bit():
     n, h, w, cin, cout = 1, 24, 64, 96, 256
     x = _to_mx(_rnd((n, cin, h, w), 27))
     wp = _pack_w(_rnd((cout, cin, 3, 3), 28, 0.03))
-    outs = [ops.conv2d(x, wp, cout, 3, 3, (1, 1), (1, 1), act=2, algo=16 + i).cpu().view(torch.uint8) for i in (0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 15)]
+    outs = [ops.conv2d(x, wp, cout, 3, 3, (1, 1), (1, 1), act=2, algo=_tile(i)).cpu().view(torch.uint8) for i in (0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 15, 16)]
     for o in outs[1:]:
         assert torch.equal(outs[0], o)
 
@@ -601,3 +607,84 @@ def test_groupnorm_partial_sums_strip_kernel_and_refusals():
     xf = ops.convert(xd, torch.float16)
     with pytest.raises(MarconetHipError):       # plain f16 storage
         ops.conv2d(xf, wt.permute(0, 2, 3, 1).contiguous().half().to(DEV), c, 3, 3, (1, 1), (1, 1), gn_partial=part)
+
+
+# ---------------------------------------------------------------------------------------------------------------- round 6
+W4 = 16     # fp16+8 LDS-DMA id 16: the 256x256 tile with ONE wave per SIMD (conv_dma_w4.hip: 4 waves x 128x128 outputs, accumulators in a[0:255])
+
+
+@pytest.mark.parametrize("case", [
+    # cout, cin, k, (n, h, w), reference id (lock-step 8-wave 256x256 tile)
+    (256, 64, 3, (4, 128, 160), 6),       # 320 pixel tiles on <= 256 workgroups: the slab stream crosses tiles, some workgroups run two
+    (256, 32, 1, (4, 128, 160), 6),       # one slab per tile: every iteration closes a tile
+    (288, 96, 3, (3, 96, 100), 6),        # cout tail (two channel tiles: the weight scales change per tile), pixel tail, images smaller than a tile row
+    (512, 512, 3, (20, 32, 32), 6),       # 144 slabs per tile, 160 tiles, two channel tiles
+    (256, 256, 3, (2, 64, 1024), 15),     # the trunk shape class (72 slabs per tile, 512 tiles) against the software-pipelined production tile
+    (256, 64, 3, (1, 8, 24), 6),          # ONE partial tile: 255 of the 256 workgroups... none: a single workgroup, 192 pixels
+    (64, 64, 3, (2, 32, 64), 6),          # cout 64: three quarters of the weight rows are out of range (zeros), nothing stored for them
+])
+def test_one_wave_per_simd_tile_equals_the_8_wave_tiles(case):
+    """round 6, id 16: the same LDS image, k order and MFMA sequence per output as ids 6 / 15 -> the same bytes, with the full epilogue (bias, residual,
+    activation), ragged widths, multi-pass persistent grids, one slab per tile, channel / pixel tails; twice (no state left behind)"""
+    ops = _ops()
+    cout, cin, k, (n, h, w), ref = case
+    x = _to_mx(_rnd((n, cin, h, w), 161))
+    wp = _pack_w(_rnd((cout, cin, k, k), 162, 1.0 / math.sqrt(cin * k * k)))
+    bias = _rnd((cout,), 163, 0.3).to(DEV)
+    res = _to_mx(_rnd((n, cout, h, w), 164))
+    vw = torch.tensor([w - 7 * (i % 3) for i in range(n)], dtype=torch.int32, device=DEV)
+    outs = []
+    for i in (ref, W4, W4):
+        y = ops.conv2d(x, wp, cout, k, k, (1, 1), (k // 2, k // 2), bias=bias, residual=res, act=3, valid_w=vw, algo=_tile(i))
+        torch.cuda.synchronize()
+        outs.append(y.cpu().view(torch.uint8))
+    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[1], outs[2])
+
+
+def test_one_wave_per_simd_tile_out_scale_post_scale_and_no_epilogue_terms():
+    """the remaining epilogue passes (per-image out_scale / post_scale: the demodulation and the next layer's style) and the bare accumulator"""
+    ops = _ops()
+    n, h, w, cin, cout = 6, 64, 64, 64, 256
+    x = _to_mx(_rnd((n, cin, h, w), 171))
+    wp = _pack_w(_rnd((cout, cin, 3, 3), 172, 1.0 / math.sqrt(cin * 9)))
+    osc, psc = (_rnd((n, cout), 173).abs() + 0.5).to(DEV), (_rnd((n, cout), 174).abs() + 0.5).to(DEV)
+    for kw in (dict(out_scale=osc, post_scale=psc, act=3, bias=_rnd((cout,), 175).to(DEV)), dict()):
+        a = ops.conv2d(x, wp, cout, 3, 3, (1, 1), (1, 1), algo=_tile(6), **kw).cpu().view(torch.uint8)
+        b = ops.conv2d(x, wp, cout, 3, 3, (1, 1), (1, 1), algo=_tile(W4), **kw).cpu().view(torch.uint8)
+        assert torch.equal(a, b)
+
+
+def test_one_wave_per_simd_tile_concat_and_folded_skip():
+    """second concat source (conv_body_32.0's shape class) and MNET_CONV_ALGO_FLAG_X1_CENTER (the fuse blocks' 1x1 skip conv as extra K)"""
+    ops = _ops()
+    from marconet_amd import _lib
+    n, h, w, c0, c1, cout = 40, 32, 64, 64, 32, 256
+    x0, x1 = _to_mx(_rnd((n, c0, h, w), 181)), _to_mx(_rnd((n, c1, h, w), 182))
+    wp = _pack_w(_rnd((cout, c0 + c1, 3, 3), 183, 1.0 / math.sqrt((c0 + c1) * 9)))
+    bias = _rnd((cout,), 184, 0.3).to(DEV)
+    vw = torch.tensor([w - 3 * (i % 4) for i in range(n)], dtype=torch.int32, device=DEV)
+    outs = [ops.conv2d(x0, wp, cout, 3, 3, (1, 1), (1, 1), x1=x1, bias=bias, act=2, valid_w=vw, algo=_tile(i)).cpu().view(torch.uint8) for i in (6, W4)]
+    assert torch.equal(outs[0], outs[1])
+    # folded skip: [cout][3][3][c0 + c1] weights whose second part is read at the centre tap only
+    outs = [ops.conv2d(x0, wp, cout, 3, 3, (1, 1), (1, 1), x1=x1, bias=bias, valid_w=vw, x1_center=True, algo=_tile(i)).cpu().view(torch.uint8) for i in (6, 15, W4)]
+    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
+
+
+@pytest.mark.parametrize("case", [(256, 64, (3, 16, 64), None), (256, 96, (4, 32, 32), [32, 17, 1, 29]), (512, 64, (40, 32, 64), None)])
+def test_one_wave_per_simd_tile_groupnorm_sums(case):
+    """mnet_conv_desc.gn_partial written by id 16's own epilogue: the same fragment bytes and output bytes as the lock-step tile (id 11 / 6)"""
+    ops = _ops()
+    cout, cin, (n, h, w), vws = case
+    x = _to_mx(_rnd((n, cin, h, w), 191))
+    wp = _pack_w(_rnd((cout, cin, 3, 3), 192, 1.0 / math.sqrt(cin * 9)))
+    bias = _rnd((cout,), 193, 0.3).to(DEV)
+    vw = None if vws is None else torch.tensor(vws, dtype=torch.int32).to(DEV)
+    got = []
+    for i in (6, W4):
+        part = ops.gn_partial_buffer(n, h, w, cout, DEV)
+        part.fill_(float("nan"))
+        y = ops.conv2d(x, wp, cout, 3, 3, (1, 1), (1, 1), bias=bias, act=2, valid_w=vw, algo=_tile(i), gn_partial=part)
+        torch.cuda.synchronize()
+        got.append((y.cpu().view(torch.uint8), part.cpu()))
+    assert torch.isfinite(got[1][1]).all()
+    assert torch.equal(got[0][0], got[1][0]) and torch.equal(got[0][1], got[1][1])

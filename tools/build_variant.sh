@@ -9,7 +9,7 @@ NAME=$1; STEM=$2; shift 2
 SRC="$ROOT/marconet_amd/csrc"; LIB="$ROOT/marconet_amd/lib"; OUT="$ROOT/tools/_build/$NAME"
 mkdir -p "$OUT"
 HIPCC="${HIPCC:-/opt/rocm/bin/hipcc}"
-ALL="api conv_igemm conv_igemm_dma conv_dma_swp_gn conv_strip_dma conv_skinny aux_kernels vit_kernels pack_kernels"
+ALL="api conv_igemm conv_igemm_dma conv_dma_swp_gn conv_dma_w4 conv_strip_dma conv_skinny aux_kernels vit_kernels pack_kernels"
 xf() { [ "$1" = conv_dma_swp_gn ] && echo "-mllvm -greedy-reverse-local-assignment=1"; }
 if [ "$STEM" = "all" ]; then
   PIDS=()
