@@ -42,7 +42,8 @@ constexpr int FA = 4, FB = 4;                         // 32x32 accumulator block
 constexpr int WJ = BC / (8 * NW), XJ = BP / (8 * NW), NDMA = WJ + XJ;     // 8 + 8 DMA pieces (1 KiB each) per wave and slab
 constexpr int STAGE = (BC + BP) * 128, STAGES = 2;
 constexpr int XB = 4096;                              // epilogue transposition scratch per wave behind the stages (dma_epilogue_mx)
-constexpr int LDS = STAGES * STAGE + NW * XB;         // 144 KiB
+constexpr int PB = 1536;                              // epilogue parameter area per wave (w4_epilogue): bias 2 x 64 floats + two step buffers of 2 x 64 floats
+constexpr int LDS = STAGES * STAGE + NW * (XB + PB);  // 150 KiB
 constexpr unsigned OOB = 0x80000000u;
 static_assert(FA * FB == NDMA, "one DMA piece behind each scaled MFMA");
 }
@@ -54,8 +55,210 @@ static_assert(FA * FB == NDMA, "one DMA piece behind each scaled MFMA");
 // W4_MFMA_ZERO: a block cleared by the matrix pipe itself (0 * 0 + 0: one 8-pass MFMA instead of 16 v_accvgpr_write, and no compiler-made zero tuple that hipcc would
 // copy into the blocks lazily, right in front of their first MFMA).
 #define W4_MFMA_F16(ACC, A, B) asm volatile("s_nop 1\n\tv_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+a"(ACC) : "v"(A), "v"(B))
+// the f16 MFMAs of the slab loop: operands straight from the LDS (s_waitcnt, no VALU write — tools/isa_mfma_hazards.py checks the built ISA: the only way one gets in is a
+// compiler copy), so no s_nop; the _P form also names a VGPR the statement does not touch: the x_hi8 conversion of the gap before it, which has no reader until the next
+// iteration and would otherwise be sunk out of its gap (one statement instead of MFMA + an empty pinning statement with its own boundary pad)
+#ifndef W4_F16_NOP
+#define W4_F16_NOP 0
+#endif
+#if W4_F16_NOP
+#define W4_MFMA_F16_HOT(ACC, A, B) W4_MFMA_F16(ACC, A, B)
+#define W4_MFMA_F16_HOT_P(ACC, A, B, P) asm volatile("s_nop 1\n\tv_mfma_f32_32x32x16_f16 %0, %2, %3, %0" : "+a"(ACC), "+v"(P) : "v"(A), "v"(B))
+#else
+#define W4_MFMA_F16_HOT(ACC, A, B) asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+a"(ACC) : "v"(A), "v"(B))
+#define W4_MFMA_F16_HOT_P(ACC, A, B, P) asm volatile("v_mfma_f32_32x32x16_f16 %0, %2, %3, %0" : "+a"(ACC), "+v"(P) : "v"(A), "v"(B))
+#endif
 #define W4_MFMA_ZERO(ACC, Z) asm volatile("s_nop 1\n\tv_mfma_f32_32x32x16_f16 %0, %1, %1, 0" : "=a"(ACC) : "v"(Z))
 #define W4_MFMA_SC(ACC, A8, B8, SA, SB) asm volatile("s_nop 1\n\tv_mfma_scale_f32_32x32x64_f8f6f4 %0, %1, %2, %0, %3, %4 op_sel_hi:[0,0,0]" : "+a"(ACC) : "v"(A8), "v"(B8), "v"(SA), "v"(SB))
+
+// Epilogue of the one-wave-per-SIMD tile: the arithmetic of dma_epilogue_mx (conv_dma_common.h) value for value — accumulator * 2^-8, out_scale, bias, residual, activation,
+// post_scale, GroupNorm sums, fp16+8 encode, store through the wave's LDS scratch — re-ordered for ONE wave per SIMD.  With two waves per SIMD the partner hides a step's
+// latencies; alone, dma_epilogue_mx's 8 steps (4 pixel fragments x 2 channel blocks per lane) cost 68 000 cycles per tile (tools/w4_phases.py, profiles/r6c_*): every step's
+// parameter loads sit behind the previous step's stores on the in-order vmcnt counter, i.e. each step waits for the write-back of the one before.  Here
+//   * the per-channel vectors go through the wave's LDS parameter area, ONE float per lane: the 64 lanes of a step need 2 x 32 values of each vector (the 32 pixels of a lane
+//     half share their 32 channels) — lane l fetches value l of the step's 64-channel window, writes it to the LDS, and every lane reads back its half's 32 values as 8
+//     broadcast ds_read_b128 (lgkmcnt: not ordered behind the stores).  The bias window is fetched once per tile (it does not depend on the pixel fragment), the
+//     out_scale / post_scale windows (rows of the fragment's image) one step ahead;
+//   * the residual block of step t + 1 (7 loads per lane) is requested BEFORE the stores of step t, so the wait in front of step t + 1's arithmetic leaves those stores in flight.
+// The one-float-per-lane form needs the 32 pixels of a fragment in ONE image (ho * wo % 32 == 0: every launch this tile is chosen for); otherwise (`rows_ok` false) the
+// out_scale / post_scale values are loaded per lane as in dma_epilogue_mx.
+// ACC::get(fa, px, q) takes a value out of the accumulator file where it is consumed.  `par`: this wave's parameter area (w4::PB bytes).
+template <bool GN, typename ACC, typename STAMP>
+__device__ __forceinline__ void w4_epilogue(const ConvArgs& p, const ACC& acc, int co0, int pix0, int wc, int wp, int lane, unsigned char* xpose, unsigned char* par, STAMP&& stamp) {
+    using namespace w4;
+    constexpr int NPX = FB, NB = FA / 2, NS = NPX * NB;
+    const int h = lane >> 5;
+    const int last_pix = p.npix - 1;
+    float* gnp = nullptr;
+    if constexpr (GN) gnp = kernarg_gn_partial();
+    const bool rows_ok = (p.howo & 31) == 0;                               // (wave-uniform)
+    int cob[NB], co[NB], co_l[NB];
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+        cob[b] = co0 + wc * (BC / WC) + b * 64;                             // first channel of lane-half 0's block
+        co[b] = cob[b] + h * 32;                                            // first channel of this lane's block
+        co_l[b] = min(co[b], p.cout - 32);                                  // (a lane whose block lies beyond cout works on the last block's parameters; nobody stores its result)
+    }
+    // LDS parameter area of this wave: [bias: NB x 64 floats][step buffer 0: out_scale 64 | post_scale 64 floats][step buffer 1].  A lane's own value of a 64-channel
+    // window sits at float index `lane`; its half's 32 values are the 8 chunks at float index 32 h.  (channels >= cout: any in-range value — those blocks are not stored)
+    float* const par_f = reinterpret_cast<float*>(par);
+    if (p.bias) {
+#pragma unroll
+        for (int b = 0; b < NB; ++b) par_f[b * 64 + lane] = p.bias[min(cob[b] + lane, p.cout - 1)];
+    }
+    struct Step { float osc1, psc1; u32x4 rh[4], rl[2]; unsigned re8; int pixb, pix, n_img; };
+    auto request = [&](int t, Step& S) __attribute__((always_inline)) {     // addresses + parameter loads of step t (no use of the values here)
+        const int px = t / NB, b = t % NB;
+        S.pixb = pix0 + wp * (BP / WP) + px * 32;                           // first pixel of this wave's 32
+        S.pix = S.pixb + (lane & 31);
+        const bool p2 = p.howo_shift >= 0;                                  // (wave-uniform) every map of this network: a shift instead of an integer division per lane and step
+        S.n_img = p2 ? min(S.pix, last_pix) >> p.howo_shift : min(S.pix, last_pix) / p.howo;
+        if (rows_ok) {                                                      // the fragment's image is wave-uniform: one float of the 64-channel window per lane
+            const int img = p2 ? min(S.pixb, last_pix) >> p.howo_shift : min(S.pixb, last_pix) / p.howo;
+            const size_t row = (size_t)img * p.cout + min(cob[b] + lane, p.cout - 1);
+            if (p.out_scale) S.osc1 = p.out_scale[row];
+            if (p.post_scale) S.psc1 = p.post_scale[row];
+        }
+        if (p.res && S.pix < p.npix) {
+            const int rpix = p.res_mod > 0 ? S.pix % p.res_mod : S.pix;
+            const unsigned char* rb = reinterpret_cast<const unsigned char*>(p.res) + (size_t)rpix * p.cout * 4 + (co_l[b] >> 5) * 128;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) S.rh[c] = ldg16(rb + c * 16);
+            S.rl[0] = ldg16(rb + 64); S.rl[1] = ldg16(rb + 80);           // lo bytes of chunks (0, 2) | (1, 3)
+            S.re8 = rb[96];
+        }
+    };
+    // every store of the epilogue is UNCONDITIONAL: a raw buffer store through a descriptor of this tile's window of the output (num_records = its valid pixels), a lane
+    // with nothing to write gets an out-of-range offset and the hardware drops it.  Stores behind `if (valid)` branches would make the number of VMEM operations issued
+    // after the next step's parameter loads path-dependent, and hipcc's s_waitcnt pass then waits with vmcnt(0) — for the stores — in front of every step (measured: 59
+    // vmcnt(0) waits per epilogue, 90 000 cycles per tile)
+    const int tile_px = min(BP, p.npix - pix0);
+    const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<unsigned char*>(p.y) + (size_t)pix0 * p.cout * 4, 0,
+                                                                         __builtin_amdgcn_readfirstlane(tile_px * p.cout * 4), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rg = __builtin_amdgcn_make_buffer_rsrc(gnp, 0, __builtin_amdgcn_readfirstlane(gnp ? (p.npix >> 5) * (p.cout >> 5) * 8 : 0), 0x00020000);
+    Step cur;
+    request(0, cur);
+    stamp(7);                                                               // (W4_STAMPS == 2: sub-phases of the epilogue, see the kernel)
+#pragma unroll
+    for (int t = 0; t < NS; ++t) {
+        const int px = t / NB, b = t % NB;
+        const int pixb = cur.pixb, pix = cur.pix, n_img = cur.n_img;
+        float* const stepbuf = par_f + NB * 64 + (t & 1) * 128;
+        if (rows_ok) {                                                      // this step's scale windows → LDS (read back below, per half)
+            if (p.out_scale) stepbuf[lane] = cur.osc1;
+            if (p.post_scale) stepbuf[64 + lane] = cur.psc1;
+        }
+        float v[32];
+#pragma unroll
+        for (int q = 0; q < 16; ++q) { v[q] = acc.get(2 * b, px, q) * MNET_SPLIT_WSCALE_INV; v[16 + q] = acc.get(2 * b + 1, px, q) * MNET_SPLIT_WSCALE_INV; }
+        // (two address spaces: an LDS-or-global pointer select would compile to flat loads, which wait on both counters)
+        auto scale32 = [&](const float* lds32, const float* glob32) __attribute__((always_inline)) {
+            if (rows_ok) {
+                typedef __attribute__((address_space(3))) const f32x4* lds_f32x4;     // (an explicit LDS pointer: the two arms cannot be merged into one load through a selected pointer)
+                const lds_f32x4 l4 = (lds_f32x4)lds32;
+#pragma unroll
+                for (int q = 0; q < 32; q += 4) { const f32x4 s4 = l4[q >> 2]; v[q] *= s4[0]; v[q + 1] *= s4[1]; v[q + 2] *= s4[2]; v[q + 3] *= s4[3]; }
+            } else {
+#pragma unroll
+                for (int q = 0; q < 32; q += 4) { const f32x4 s4 = *reinterpret_cast<const f32x4*>(glob32 + q); v[q] *= s4[0]; v[q + 1] *= s4[1]; v[q + 2] *= s4[2]; v[q + 3] *= s4[3]; }
+            }
+        };
+        if (p.out_scale) scale32(stepbuf + 32 * h, p.out_scale + (size_t)n_img * p.cout + co_l[b]);
+        if (p.bias) {
+            const float* bp = par_f + b * 64 + 32 * h;
+#pragma unroll
+            for (int q = 0; q < 32; q += 4) { const f32x4 b4 = *reinterpret_cast<const f32x4*>(bp + q); v[q] += b4[0]; v[q + 1] += b4[1]; v[q + 2] += b4[2]; v[q + 3] += b4[3]; }
+        }
+        if (p.res && pix < p.npix) {
+            const float sl = hm_lo_scale((int)cur.re8);
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const f16x8 h8 = bitcast<f16x8>(cur.rh[c]);
+                float l[8];
+                hm_decode_lo(u32x2{cur.rl[c & 1][2 * (c >> 1)], cur.rl[c & 1][2 * (c >> 1) + 1]}, sl, l);      // slot of chunk c = hm_lo_slot(c) = 2 (c & 1) + (c >> 1)
+#pragma unroll
+                for (int q = 0; q < 8; ++q) v[c * 8 + q] += (float)h8[q] + l[q];
+            }
+        }
+        act_apply_vec<32, true>(v, p.act);
+        if (p.post_scale) scale32(stepbuf + 64 + 32 * h, p.post_scale + (size_t)n_img * p.cout + co_l[b]);
+        // GroupNorm statistics of this output, part 1 (see dma_epilogue_mx): two fp32 sums per lane over its 32 channels of ONE group
+        float gs1 = 0.f, gs2 = 0.f;
+        if (GN && gnp) {
+#pragma unroll
+            for (int q = 0; q < 32; ++q) { gs1 += v[q]; gs2 = fmaf(v[q], v[q], gs2); }
+        }
+        f16x8 hh[4];
+        float m32 = 0.f;
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+#pragma unroll
+            for (int q = 0; q < 8; ++q) { hh[c][q] = (f16)v[c * 8 + q]; m32 = fmaxf(m32, fabsf(v[c * 8 + q])); }
+        const float m = (float)(f16)m32;
+        const int e8 = hm_e8_of(m);
+        u32x2 lo[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) lo[c] = hm_encode_lo_ref(v + c * 8, hh[c], e8);
+        stamp(8);
+        // the NEXT step's parameters are requested here — in front of this step's stores on the vmcnt counter
+        Step nxt = cur;
+        if (t + 1 < NS) request(t + 1, nxt);
+        stamp(9);
+        // ---- through the LDS: two rounds of 4 pieces per lane (the hi halves, then lo bytes | lo bytes | scale | padding), see dma_epilogue_mx
+        const unsigned L = (unsigned)lane;
+        const unsigned wsw = (L >> 1) & 3u, j = L & 3u;
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+            u32x4 pc[4];
+            if (half == 0) {
+#pragma unroll
+                for (int c = 0; c < 4; ++c) pc[c] = bitcast<u32x4>(hh[c]);
+            } else {
+                pc[0] = u32x4{lo[0][0], lo[0][1], lo[2][0], lo[2][1]};
+                pc[1] = u32x4{lo[1][0], lo[1][1], lo[3][0], lo[3][1]};
+                pc[2] = u32x4{(unsigned)e8, 0u, 0u, 0u};
+                pc[3] = u32x4{0u, 0u, 0u, 0u};
+            }
+#pragma unroll
+            for (int c = 0; c < 4; ++c) *reinterpret_cast<u32x4*>(xpose + ((4u * L + ((unsigned)c ^ wsw)) << 4)) = pc[c];
+            u32x4 piece[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const unsigned P = (L >> 2) + 16u * k;                      // the lane whose block this lane helps to write
+                piece[k] = *reinterpret_cast<const u32x4*>(xpose + ((4u * P + (j ^ ((P >> 1) & 3u))) << 4));
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) asm volatile("" : "+v"(piece[k]));   // all four reads in flight
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const unsigned P = (L >> 2) + 16u * k;
+                const int ppix = pixb + (int)(P & 31u), pco = cob[b] + (int)(P >> 5) * 32;
+                // (pixels >= npix lie beyond the descriptor's num_records; a block beyond cout gets bit 31)
+                const unsigned off = (unsigned)((ppix - pix0) * p.cout * 4 + (pco >> 5) * 128 + half * 64) + j * 16u;
+                __builtin_amdgcn_raw_buffer_store_b128(piece[k], ry, (int)(pco < p.cout ? off : OOB), 0, 0);
+            }
+            stamp(10 + half);
+        }
+        if constexpr (GN) {
+            // part 2: a fixed xor tree over the 32 pixels of the lane half, one 8-byte store per (32 pixels, group) — the fragment and the tree of every fp16+8 tile
+            if (gnp) {
+                bool ok = pix < p.npix && co[b] < p.cout;
+                if (p.valid_w) {
+                    const int ow = p.wo_shift >= 0 ? (pix & (p.wo - 1)) : pix % p.wo;
+                    ok = ok && ow < p.valid_w[n_img];
+                }
+                gs1 = ok ? gs1 : 0.f; gs2 = ok ? gs2 : 0.f;
+#pragma unroll
+                for (int o = 1; o < 32; o <<= 1) { gs1 += __shfl_xor(gs1, o, 64); gs2 += __shfl_xor(gs2, o, 64); }
+                const bool wr = (lane & 31) == 0 && pixb < p.npix && co[b] < p.cout;
+                const unsigned goff = (unsigned)(((pixb >> 5) * (p.cout >> 5) + (co[b] >> 5)) * 8);
+                __builtin_amdgcn_raw_buffer_store_b64(u32x2{__builtin_bit_cast(unsigned, gs1), __builtin_bit_cast(unsigned, gs2)}, rg, (int)(wr ? goff : OOB), 0, 0);
+            }
+        }
+        stamp(12);
+        cur = nxt;
+    }
+}
 
 __global__ void __launch_bounds__(256, 1) conv_dma_w4_kernel(const ConvArgs p) {
     using namespace w4;
@@ -166,16 +369,23 @@ __global__ void __launch_bounds__(256, 1) conv_dma_w4_kernel(const ConvArgs p) {
     // wave-uniform parts of a slab's addresses, formed once per slab; a slab that does not exist (end of the stream) is issued with out-of-range offsets
     __amdgpu_buffer_rsrc_t sl_rW, sl_rX;
     unsigned sl_kb = 0, sl_tap = 0, sl_cb = 0, sl_uni = 0, sl_dead = 0;
-    auto sw_slab = [&](bool more) __attribute__((always_inline)) {
-        const bool second = cur_c >= p.c0;                           // wave-uniform: second concat source
+    // (three parts: inside the slab loop each goes behind its own MFMA of the f16 part's second k-step — ~12 scalar instructions fit under one 32-cycle MFMA, 40 do not)
+    auto sw_slab_a = [&](bool more) __attribute__((always_inline)) {
         sl_rW = __builtin_amdgcn_make_buffer_rsrc((void*)uni64(bW), 0, __builtin_amdgcn_readfirstlane(nW), 0x00020000);
-        sl_rX = __builtin_amdgcn_make_buffer_rsrc((void*)uni64(second ? bX1 : bX0), 0, __builtin_amdgcn_readfirstlane(second ? nX1 : nX0), 0x00020000);
         sl_kb = (unsigned)(cur_tap * p.cin + cur_c) * 2u;
         sl_tap = (unsigned)cur_tap;
-        sl_cb = (unsigned)(second ? p.c1 : p.c0) * 2u;
-        sl_uni = (unsigned)(cur_tpx * (int)sl_cb + (second ? cur_c - p.c0 : cur_c) * 2) + lcb;
         sl_dead = more ? 0u : OOB;
     };
+    auto sw_slab_b = [&]() __attribute__((always_inline)) {
+        const bool second = cur_c >= p.c0;                           // wave-uniform: second concat source
+        sl_rX = __builtin_amdgcn_make_buffer_rsrc((void*)uni64(second ? bX1 : bX0), 0, __builtin_amdgcn_readfirstlane(second ? nX1 : nX0), 0x00020000);
+    };
+    auto sw_slab_c = [&]() __attribute__((always_inline)) {
+        const bool second = cur_c >= p.c0;
+        sl_cb = (unsigned)(second ? p.c1 : p.c0) * 2u;
+        sl_uni = (unsigned)(cur_tpx * (int)sl_cb + (second ? cur_c - p.c0 : cur_c) * 2) + lcb;
+    };
+    auto sw_slab = [&](bool more) __attribute__((always_inline)) { sw_slab_a(more); sw_slab_b(); sw_slab_c(); };
     auto sw_piece = [&](int idx) __attribute__((always_inline)) {
         unsigned char* sw_ = smem + i_stage * STAGE;
         if (idx < WJ) {
@@ -196,12 +406,13 @@ __global__ void __launch_bounds__(256, 1) conv_dma_w4_kernel(const ConvArgs p) {
         ++i_kt;
     };
 
-    unsigned ph_sum[7] = {0u, 0u, 0u, 0u, 0u, 0u, 0u}, ph_prev = 0u, ph_slabs = 0u, ph_tiles = 0u;
+    unsigned ph_sum[13] = {0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u}, ph_prev = 0u, ph_slabs = 0u, ph_tiles = 0u;
+    bool ph_on = false;                                  // (iteration 0 runs the f16 part before the loop's first stamp: not booked)
     auto ph_stamp = [&](int i) __attribute__((always_inline)) {
         if constexpr (W4_STAMPS != 0) {
             __builtin_amdgcn_sched_barrier(0);
             const unsigned t = (unsigned)__builtin_readcyclecounter();
-            if (i >= 0) ph_sum[i] += t - ph_prev;
+            if (i >= 0 && ph_on) ph_sum[i] += t - ph_prev;
             ph_prev = t;
             __builtin_amdgcn_sched_barrier(0);
         }
@@ -284,9 +495,18 @@ __global__ void __launch_bounds__(256, 1) conv_dma_w4_kernel(const ConvArgs p) {
         // behind MFMA i:  i < 2 FA: one fp8-side weight read (lo8 / hi8 chunk of fragment i / 2);  i < FA FB, last pixel fragment of a row: the second k-step's
         // weight fragment;  i < 4 FB: one x_hi8 conversion group (2 v_cvt_scalef32_pk_fp8_f16 of 16 channels' halves; first k-step first)
         constexpr int NM = 2 * FA * FB;
+        int cvp = 0;                                     // the conversion result of the gap before (named by the next MFMA statement, then filed into b8)
         auto step = [&](int i) __attribute__((always_inline)) {
             const int k2 = i / (FA * FB), fa = (i % (FA * FB)) / FB, fb = i % FB;
-            W4_MFMA_F16(acc[fa][fb], a[k2][fa], bh[k2][fb]);
+            if (i >= 1 && i - 1 < 4 * FB) {
+                W4_MFMA_F16_HOT_P(acc[fa][fb], a[k2][fa], bh[k2][fb], cvp);
+                const int g = i - 1, kk = g / (2 * FB), f = (g >> 1) % FB, d = g & 1;
+                b8[f][2 * kk + d] = cvp;
+            } else if (W4_PREP_IN_F16 && i > FA * FB && i <= FA * FB + 5) {
+                W4_MFMA_F16(acc[fa][fb], a[k2][fa], bh[k2][fb]);       // behind a book-keeping part (control flow joins in front of it): padded
+            } else {
+                W4_MFMA_F16_HOT(acc[fa][fb], a[k2][fa], bh[k2][fb]);
+            }
             if (i < 2 * FA || i < 4 * FB || (i < FA * FB && fb == FB - 1)) {
                 __builtin_amdgcn_sched_barrier(0);
                 if (i < 2 * FA) {
@@ -300,12 +520,10 @@ __global__ void __launch_bounds__(256, 1) conv_dma_w4_kernel(const ConvArgs p) {
                 if (i < 4 * FB) {
                     const int kk = i / (2 * FB), f = (i >> 1) % FB, d = i & 1;
                     const float sc = __builtin_bit_cast(float, (unsigned)ebn[f] << 23);
-                    s16x2 r = {0, 0};
+                    s16x2 r = bitcast<s16x2>(b8[f][2 * kk + d]);      // (the destination's stale bytes as the tied operand: both halves are overwritten, no zeroing move)
                     r = __builtin_amdgcn_cvt_scalef32_pk_fp8_f16(r, bitcast<f16x2>(bh[kk][f][2 * d]), sc, false);
                     r = __builtin_amdgcn_cvt_scalef32_pk_fp8_f16(r, bitcast<f16x2>(bh[kk][f][2 * d + 1]), sc, true);
-                    int r32 = bitcast<int>(r);
-                    asm volatile("" : "+v"(r32));            // pinned HERE: the value has no reader before the next iteration and LLVM sinks it past the control flow of prep()
-                    b8[f][2 * kk + d] = r32;
+                    cvp = bitcast<int>(r);                                 // filed into b8 behind the next MFMA statement, which names it (see W4_MFMA_F16_HOT_P)
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
@@ -313,14 +531,21 @@ __global__ void __launch_bounds__(256, 1) conv_dma_w4_kernel(const ConvArgs p) {
 #pragma unroll
         for (int i = 0; i <= FA * FB; ++i) step(i);
         ph_stamp(2);
-        if (W4_PREP_IN_F16) {               // behind the first MFMA of the second k-step (outside the unrolled loops: the tile crossing's set-up is a large block)
-            __builtin_amdgcn_sched_barrier(0);
-            prep();
-            __builtin_amdgcn_sched_barrier(0);
-        }
+        // the second k-step is 16 MFMAs with nothing else to issue: the slab stream's scalar book-keeping — cursor advance of the slab whose pieces went out in this
+        // iteration, then the next slab's address parts (a tile crossing's set-up included: a large block, once per tile) — goes behind its first MFMAs, one part each
+        auto fence = [&](auto&& f) __attribute__((always_inline)) { __builtin_amdgcn_sched_barrier(0); f(); __builtin_amdgcn_sched_barrier(0); };
+        if (W4_PREP_IN_F16) fence([&]() __attribute__((always_inline)) { if (more) sw_end(); });
+        step(FA * FB + 1);
+        if (W4_PREP_IN_F16) fence([&]() __attribute__((always_inline)) { more = sw_begin(); });
+        step(FA * FB + 2);
+        if (W4_PREP_IN_F16) fence([&]() __attribute__((always_inline)) { sw_slab_a(more); });
+        step(FA * FB + 3);
+        if (W4_PREP_IN_F16) fence([&]() __attribute__((always_inline)) { sw_slab_b(); });
+        step(FA * FB + 4);
+        if (W4_PREP_IN_F16) fence([&]() __attribute__((always_inline)) { sw_slab_c(); });
         ph_stamp(3);
 #pragma unroll
-        for (int i = FA * FB + 1; i < NM; ++i) step(i);
+        for (int i = FA * FB + 5; i < NM; ++i) step(i);
     };
     // the wait states a 16-pass MFMA's result needs before a VALU (v_accvgpr_read of the epilogue) may read it: hipcc pads nothing behind an asm statement
     auto mfma_drain = [&]() __attribute__((always_inline)) { asm volatile("s_nop 15\n\ts_nop 7" ::: "memory"); };
@@ -338,7 +563,9 @@ __global__ void __launch_bounds__(256, 1) conv_dma_w4_kernel(const ConvArgs p) {
         int co0, pix0;
         tile_coords(v, co0, pix0);
         mfma_drain();
-        dma_epilogue_mx_acc<BC, BP, WC, WP, 2 * FA, 2 * FB, 64, true>(p, AccFile{acc}, co0, pix0, wc, wp, lane, xpose);
+        // (W4_STAMPS == 2: slots 7-12 = per tile: first request | per step, summed: arithmetic + encode | next step's requests | LDS round + stores 1 | 2 | GroupNorm fold)
+        w4_epilogue<true>(p, AccFile{acc}, co0, pix0, wc, wp, lane, xpose, smem + STAGES * STAGE + NW * XB + wave * PB,
+                          [&](int i) __attribute__((always_inline)) { if constexpr (W4_STAMPS == 2) ph_stamp(i); });
     };
 
     setup(i_v);
@@ -358,11 +585,12 @@ __global__ void __launch_bounds__(256, 1) conv_dma_w4_kernel(const ConvArgs p) {
     prep();
 #pragma unroll
     for (int idx = 0; idx < NDMA; ++idx) sw_piece(idx);
-    if (more) sw_end();
+    if (!W4_PREP_IN_F16 && more) sw_end();                           // (W4_PREP_IN_F16: inside the f16 part)
     __builtin_amdgcn_sched_barrier(0);
     f16_part(0u);
     c_kt = 1;
     ph_stamp(-1);
+    ph_on = true;
     for (int s = 1; s < total; ++s) {
         VMCNT(0);                                                    // this wave's pieces of slab s (and the previous epilogue's stores) have landed ...
         ph_stamp(5);
@@ -376,7 +604,7 @@ __global__ void __launch_bounds__(256, 1) conv_dma_w4_kernel(const ConvArgs p) {
         __builtin_amdgcn_sched_barrier(0);
         scaled_prev(std::true_type{}, std::integral_constant<bool, W4_FRONT_INTERLEAVED != 0>{}, so);
         ph_stamp(0);
-        if (more) sw_end();
+        if (!W4_PREP_IN_F16 && more) sw_end();
         if (c_kt == nk) {
             ++ph_tiles;                                            // slab s-1 closed its tile: epilogue, then the next tile's scales and a clean accumulator
             epilogue(c_v);
@@ -397,11 +625,10 @@ __global__ void __launch_bounds__(256, 1) conv_dma_w4_kernel(const ConvArgs p) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         if (lane == 0) {
-            unsigned* o = reinterpret_cast<unsigned*>(p.y) + ((size_t)blockIdx.x * NW + wave) * 16;
+            unsigned* o = reinterpret_cast<unsigned*>(p.y) + ((size_t)blockIdx.x * NW + wave) * 16;     // (64 bytes per wave)
             o[0] = 0x5157a3b7u; o[1] = ph_slabs; o[2] = ph_tiles;
 #pragma unroll
-            for (int i = 0; i < 7; ++i) o[3 + i] = ph_sum[i];
-            o[10] = __builtin_amdgcn_s_getreg((31 << 11) | 4);        // HW_ID
+            for (int i = 0; i < 13; ++i) o[3 + i] = ph_sum[i];
         }
     }
 }

@@ -50,7 +50,7 @@ def main():
         return
     r = raw[ok].double()
     slabs, tiles = r[:, 1], r[:, 2]
-    tot = r[:, 3:10].sum(1) / slabs
+    tot = r[:, 3:16].sum(1) / slabs
     nk = 9 * 2 * cin // 64
     print("%d wave records; hot slabs per wave %.0f, tiles closed per wave %.1f; cycles per slab (mean over waves) %.0f [min %.0f max %.0f]; 2048 of them are matrix-pipe work"
           % (int(ok.sum()), slabs.mean(), tiles.mean(), tot.mean(), tot.min(), tot.max()))
@@ -58,6 +58,11 @@ def main():
     for k, nm in enumerate(NAMES):
         v = r[:, 3 + k] / slabs
         print("  %-62s %7.0f cycles (%4.1f %%)   by wave: %s" % (nm, v.mean(), 100 * v.mean() / tot.mean(), " ".join("%6.0f" % v[wave_id == j].mean() for j in range(4))))
+    if r[:, 10:16].sum() > 0:      # -DW4_STAMPS=2: sub-phases of the epilogue (phase 1 then holds only what is left outside them)
+        sub = ["first step's parameter requests (per tile)", "accumulator reads + parameters + arithmetic + encode (8 steps)", "next step's requests (8 steps)",
+               "LDS round 1 + stores (8 steps)", "LDS round 2 + stores (8 steps)", "GroupNorm fold + store (8 steps)"]
+        for k, nm in enumerate(sub):
+            print("    epilogue: %-66s %8.0f cycles per tile" % (nm, (r[:, 10 + k] / tiles.clamp(min=1)).mean()))
     print("slabs per tile %d: phase 1 per TILE %.0f cycles (epilogue + zeroing), phase 3 per tile beyond %d x the ordinary prep: see the per-slab figure"
           % (nk, (r[:, 4] / tiles.clamp(min=1)).mean(), nk))
 
