@@ -77,7 +77,7 @@ DTPEAK = {0: PEAK_F32_TFLOPS, 1: PEAK_F16_TFLOPS, 2: PEAK_F16X3_TFLOPS, 3: PEAK_
 PDT = {"fp32": 0, "fp16": 1, "fp16x3": 2, "fp16x2": 3}
 # sources whose content decides the dominant kernel's HBM traffic: the PMC figure in profiles/pmc_traffic.json is reported
 # only while these files are the ones it was measured on (else it is stale and `traffic` is null)
-KERNEL_SOURCES = ["marconet_amd/csrc/conv_igemm_dma.hip", "marconet_amd/csrc/conv_dma_common.h", "marconet_amd/csrc/conv_args.h"]
+KERNEL_SOURCES = ["marconet_amd/csrc/conv_igemm_dma.hip", "marconet_amd/csrc/conv_dma_w4.hip", "marconet_amd/csrc/conv_dma_common.h", "marconet_amd/csrc/conv_args.h"]
 
 
 def kernel_sources_sha():

@@ -275,7 +275,16 @@ __device__ __forceinline__ void hm_decode8(u32x4 hi, u32x2 lo8, float sl, float*
 }
 template <> __device__ __forceinline__ void unpackr<hm>(const Raw<hm>& r, float* o) { hm_decode8(r.hi, r.lo8, hm_lo_scale(r.e8), o); }
 // E8M0 byte of the block scale from the block's max |hi| (as a float): 2^(floor(log2 m) - 7)
-__device__ __forceinline__ int hm_e8_of(float m) { return max(0, (int)((__builtin_bit_cast(unsigned, m) >> 23) & 255u) - 7); }
+// (raw form: the weight packer clamps it to its own range)
+__device__ __forceinline__ int hm_e8_raw(float m) { return max(0, (int)((__builtin_bit_cast(unsigned, m) >> 23) & 255u) - 7); }
+// Activation blocks: floored at 2^(-15 - 7) for a non-zero block (round 6).  Below 2^-14 the hi halves are fp16 SUBNORMALS: their rounding error stops shrinking with the
+// block (2^-25 at most), so lo * 2^11 / s grows as the block shrinks and leaves e4m3's range for max |hi| < 2^-15 — where v_cvt_pk_fp8_f32 / v_cvt_scalef32_pk_fp8_f32
+// return NaN (0x7f), not the saturated byte (measured: tests/test_round6_gpu.py).  With the floor the scaled residual is at most 2^8; nothing is lost: the
+// lo byte's resolution at the floor, 2^-36, is far below the hi half's own 2^-25.  An all-zero block keeps exponent byte 0 (lo bytes 0).
+__device__ __forceinline__ int hm_e8_of(float m) {
+    const int e = (int)((__builtin_bit_cast(unsigned, m) >> 23) & 255u) - 7;
+    return e > 0 ? max(e, 105) : 0;
+}
 // 8 lo bytes: e4m3((v - hi) * 2^11 / s), s = 2^(e8 - 127)
 __device__ __forceinline__ u32x2 hm_encode_lo_ref(const float* o, const f16x8& h, int e8) {
     const float inv = e8 >= 11 ? __builtin_bit_cast(float, (unsigned)(265 - e8) << 23) : 0.f;      // 2^(11 + 127 - e8)

@@ -43,7 +43,8 @@ constexpr int WJ = BC / (8 * NW), XJ = BP / (8 * NW), NDMA = WJ + XJ;     // 8 +
 constexpr int STAGE = (BC + BP) * 128, STAGES = 2;
 constexpr int XB = 4096;                              // epilogue transposition scratch per wave behind the stages (dma_epilogue_mx)
 constexpr int PB = 1536;                              // epilogue parameter area per wave (w4_epilogue): bias 2 x 64 floats + two step buffers of 2 x 64 floats
-constexpr int LDS = STAGES * STAGE + NW * (XB + PB);  // 150 KiB
+constexpr int TAB_MAX = 512;                          // k-slabs per tile the slab table holds (16 bytes each); the launcher hands longer k loops to the 8-wave tile
+constexpr int LDS = STAGES * STAGE + NW * (XB + PB) + TAB_MAX * 16;   // 158 KiB
 constexpr unsigned OOB = 0x80000000u;
 static_assert(FA * FB == NDMA, "one DMA piece behind each scaled MFMA");
 }
@@ -84,13 +85,22 @@ static_assert(FA * FB == NDMA, "one DMA piece behind each scaled MFMA");
 // out_scale / post_scale values are loaded per lane as in dma_epilogue_mx.
 // ACC::get(fa, px, q) takes a value out of the accumulator file where it is consumed.  `par`: this wave's parameter area (w4::PB bytes).
 template <bool GN, typename ACC, typename STAMP>
-__device__ __forceinline__ void w4_epilogue(const ConvArgs& p, const ACC& acc, int co0, int pix0, int wc, int wp, int lane, unsigned char* xpose, unsigned char* par, STAMP&& stamp) {
+__device__ __forceinline__ void w4_epilogue(const ConvArgs& p_, const ACC& acc, int co0, int pix0, int wc, int wp, int lane, unsigned char* xpose, unsigned char* par, STAMP&& stamp) {
     using namespace w4;
     constexpr int NPX = FB, NB = FA / 2, NS = NPX * NB;
     const int h = lane >> 5;
+#if defined(W4_EPI_PLAIN) && W4_EPI_PLAIN      // EXPERIMENT (wrong for launches with scales / residual / sums): what a bias + activation only epilogue costs
+    ConvArgs p = p_;
+    p.out_scale = nullptr; p.post_scale = nullptr; p.res = nullptr;
+#else
+    const ConvArgs& p = p_;
+#endif
     const int last_pix = p.npix - 1;
     float* gnp = nullptr;
     if constexpr (GN) gnp = kernarg_gn_partial();
+#if defined(W4_EPI_PLAIN) && W4_EPI_PLAIN
+    gnp = nullptr;
+#endif
     const bool rows_ok = (p.howo & 31) == 0;                               // (wave-uniform)
     int cob[NB], co[NB], co_l[NB];
 #pragma unroll
@@ -281,8 +291,12 @@ __global__ void __launch_bounds__(256, 1) conv_dma_w4_kernel(const ConvArgs p) {
     };
 
     // ================================================================== DMA issue side: one slab stream over all tiles (the addresses of conv_dma_kernel<..., MX>)
-    unsigned long long bW = 0, bX0 = 0, bX1 = 0;
-    int nW = 0, nX0 = 0, nX1 = 0;
+    // buffer descriptors of the tile being streamed (weights; first / second concat source), built ONCE per tile by setup() through readfirstlane (provably in SGPRs: a
+    // descriptor hipcc believes divergent gets a waterfall loop around every DMA) — conv_dma_kernel rebuilds them per slab, ~25 scalar instructions this tile's single
+    // wave per SIMD has no partner to hide.  After the last slab of the stream they are swapped for `dnull` (num_records = 0): the surplus pieces of the software
+    // pipeline then write zeros into a stage nobody reads, without an "| dead" on every offset.
+    const __amdgpu_buffer_rsrc_t dnull = __builtin_amdgcn_make_buffer_rsrc((void*)nullptr, 0, 0, 0x00020000);
+    __amdgpu_buffer_rsrc_t dW = dnull, dX0 = dnull, dX1 = dnull;
     auto uni64 = [](unsigned long long v) __attribute__((always_inline)) -> unsigned long long {
         const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
         return ((unsigned long long)hi << 32) | lo;
@@ -292,7 +306,11 @@ __global__ void __launch_bounds__(256, 1) conv_dma_w4_kernel(const ConvArgs p) {
     unsigned xpx[XJ], xinv[XJ];                          // activation rows: input pixel of tap 0 (relative to the tile's first image); INVERTED valid-tap bits
     // row (wave + NW j)*8 + rg → (row >> 1) & 7 = 4*(wave & 1) + (rg >> 1) for every j (NW is even)
     const unsigned lcb = (unsigned)((pc ^ (((wave & 1) << 2) + (rg >> 1))) << 4);
-    int cur_c = 0, cur_s = 0, cur_tap = 0, cur_tpx = 0;  // wave-uniform k-slab cursor
+    // The k-slab sequence of a tile — 64-channel slice outer, filter tap inner; with p.x1_center the slices of the second source one slab each, at the centre tap — is the
+    // same for every tile of the launch: its per-slab address parts are tabulated ONCE, in the LDS, by the whole workgroup (slab_table below).  conv_dma_kernel advances a
+    // cursor (tap, column, input-pixel offset, slice) and re-derives the parts per slab: ~60 scalar instructions and a dozen branches that a lone wave per SIMD cannot hide.
+    //   entry kt = { weight k byte offset, activation byte offset of (tap, slice) without the lane's chunk, 31 - tap | second source << 16, bytes per pixel of the source }
+    unsigned char* const tab = smem + STAGES * STAGE + NW * (XB + PB);
     const long long img0 = (long long)p.h * p.w * p.c0 * 2, img1 = (long long)p.h * p.w * p.c1 * 2;
 
     unsigned rowrep = 0;                                 // bit r * kw for every filter row r
@@ -303,16 +321,19 @@ __global__ void __launch_bounds__(256, 1) conv_dma_w4_kernel(const ConvArgs p) {
         int co0, pix0;
         tile_coords(v, co0, pix0);
         const long long wbytes = (long long)(p.cout - co0) * p.K * 2;
-        bW = (unsigned long long)(reinterpret_cast<const f16*>(p.wgt) + (size_t)co0 * p.K);
-        nW = (int)(wbytes < 0x7fffffffLL ? wbytes : 0x7fffffffLL);
+        const unsigned long long bW = (unsigned long long)(reinterpret_cast<const f16*>(p.wgt) + (size_t)co0 * p.K);
+        const int nW = (int)(wbytes < 0x7fffffffLL ? wbytes : 0x7fffffffLL);
         const bool p2 = p.howo_shift >= 0 && p.wo_shift >= 0;
         const int n_first = p2 ? pix0 >> p.howo_shift : pix0 / p.howo;
         const int n_last = p2 ? (min(pix0 + BP, p.npix) - 1) >> p.howo_shift : (min(pix0 + BP, p.npix) - 1) / p.howo;
         const int nimg = n_last - n_first + 1;
-        bX0 = (unsigned long long)(reinterpret_cast<const char*>(p.x0) + (size_t)n_first * img0);
-        nX0 = (int)(img0 * nimg);
-        bX1 = (unsigned long long)(p.x1 ? reinterpret_cast<const char*>(p.x1) + (size_t)n_first * img1 : reinterpret_cast<const char*>(p.x0));
-        nX1 = (int)(p.x1 ? img1 * nimg : 0);
+        const unsigned long long bX0 = (unsigned long long)(reinterpret_cast<const char*>(p.x0) + (size_t)n_first * img0);
+        const int nX0 = (int)(img0 * nimg);
+        const unsigned long long bX1 = (unsigned long long)(p.x1 ? reinterpret_cast<const char*>(p.x1) + (size_t)n_first * img1 : reinterpret_cast<const char*>(p.x0));
+        const int nX1 = (int)(p.x1 ? img1 * nimg : 0);
+        dW = __builtin_amdgcn_make_buffer_rsrc((void*)uni64(bW), 0, __builtin_amdgcn_readfirstlane(nW), 0x00020000);
+        dX0 = __builtin_amdgcn_make_buffer_rsrc((void*)uni64(bX0), 0, __builtin_amdgcn_readfirstlane(nX0), 0x00020000);
+        dX1 = __builtin_amdgcn_make_buffer_rsrc((void*)uni64(bX1), 0, __builtin_amdgcn_readfirstlane(nX1), 0x00020000);
         if (co0 != woff_co0) {                                          // (wave-uniform; one channel tile: computed once per launch)
             woff_co0 = co0;
 #pragma unroll
@@ -344,64 +365,68 @@ __global__ void __launch_bounds__(256, 1) conv_dma_w4_kernel(const ConvArgs p) {
             xpx[j] = pix < p.npix ? (unsigned)px : 0u;
             xinv[j] = ~(live ? cm * rr : 0u);
         }
-        cur_c = 0; cur_s = 0; cur_tap = 0; cur_tpx = 0;
     };
-    auto advance_cursor = [&]() __attribute__((always_inline)) {
-        if (p.x1_center && cur_c >= p.c0) { cur_c += 64; return; }
-        ++cur_tap;
-        if (++cur_s == p.kw) { cur_s = 0; cur_tpx += p.w - (p.kw - 1); } else { ++cur_tpx; }
-        if (cur_tap == p.kh * p.kw) {
-            cur_tap = 0; cur_s = 0; cur_tpx = 0; cur_c += 64;
-            if (p.x1_center && cur_c >= p.c0) { cur_tap = p.center_tap; cur_tpx = p.center_tpx; }
+    {   // slab_table: entry kt by closed form (thread t takes kt = t, t + 256, ...)
+        const int ntaps = p.kh * p.kw, first = p.x1_center ? ntaps * (p.c0 / 64) : nk;      // slabs that walk all taps
+        for (int kt = tid; kt < nk; kt += NW * 64) {
+            int tap, c;
+            if (kt < first) { tap = kt % ntaps; c = (kt / ntaps) * 64; }
+            else { tap = p.center_tap; c = p.c0 + (kt - first) * 64; }
+            const int tpx = (tap / p.kw) * p.w + tap % p.kw;               // input-pixel offset of the tap relative to tap 0 (centre tap: p.center_tpx)
+            const bool second = c >= p.c0;
+            const unsigned cb = (unsigned)(second ? p.c1 : p.c0) * 2u;
+            u32x4 e;
+            e[0] = (unsigned)(tap * p.cin + c) * 2u;
+            e[1] = (unsigned)(tpx * (int)cb + (second ? c - p.c0 : c) * 2);
+            e[2] = (31u - (unsigned)tap) | (second ? 0x10000u : 0u);
+            e[3] = cb;
+            *reinterpret_cast<u32x4*>(tab + kt * 16) = e;
         }
-    };
+        __syncthreads();
+    }
 
     int i_v = blockIdx.x, i_kt = 0, i_stage = 0;         // head of the slab stream: tile, slab, LDS stage
     bool i_live = true;
+    bool ph_crossed = false;                             // (W4_STAMPS: this iteration's book-keeping crossed into the next tile)
     auto sw_begin = [&]() __attribute__((always_inline)) -> bool {
         if (i_kt == nk) {
+            if constexpr (W4_STAMPS != 0) ph_crossed = true;
             i_kt = 0; i_v += G;
             i_live = i_v < ntiles;
             if (i_live) setup(i_v);
+            else { dW = dnull; dX0 = dnull; dX1 = dnull; }           // end of the stream: every further piece is out of range
         }
         return i_live;
     };
     // wave-uniform parts of a slab's addresses, formed once per slab; a slab that does not exist (end of the stream) is issued with out-of-range offsets
-    __amdgpu_buffer_rsrc_t sl_rW, sl_rX;
-    unsigned sl_kb = 0, sl_tap = 0, sl_cb = 0, sl_uni = 0, sl_dead = 0;
-    // (three parts: inside the slab loop each goes behind its own MFMA of the f16 part's second k-step — ~12 scalar instructions fit under one 32-cycle MFMA, 40 do not)
-    auto sw_slab_a = [&](bool more) __attribute__((always_inline)) {
-        sl_rW = __builtin_amdgcn_make_buffer_rsrc((void*)uni64(bW), 0, __builtin_amdgcn_readfirstlane(nW), 0x00020000);
-        sl_kb = (unsigned)(cur_tap * p.cin + cur_c) * 2u;
-        sl_tap = (unsigned)cur_tap;
-        sl_dead = more ? 0u : OOB;
+    // the address parts of the slab whose pieces go out next: fetched from the table (sw_fetch, one broadcast ds_read_b128) and unpacked (sw_slab) in two places of the f16
+    // part, so that the read's latency passes under an MFMA.  They stay in VGPRs (wave-uniform values): only the choice of the source descriptor needs a scalar
+    __amdgpu_buffer_rsrc_t sl_rX = dnull;
+    u32x4 sl_e = {0u, 0u, 0u, 0u};
+    unsigned sl_kb = 0, sl_sh = 0, sl_cb = 0, sl_uni = 0;
+    auto sw_fetch = [&]() __attribute__((always_inline)) { sl_e = *reinterpret_cast<const u32x4*>(tab + i_kt * 16); };
+    auto sw_slab = [&]() __attribute__((always_inline)) {
+        sl_kb = sl_e[0];
+        sl_uni = sl_e[1] + lcb;
+        sl_sh = sl_e[2] & 0xffffu;
+        sl_cb = sl_e[3];
+        sl_rX = __builtin_amdgcn_readfirstlane(sl_e[2] >> 16) ? dX1 : dX0;
     };
-    auto sw_slab_b = [&]() __attribute__((always_inline)) {
-        const bool second = cur_c >= p.c0;                           // wave-uniform: second concat source
-        sl_rX = __builtin_amdgcn_make_buffer_rsrc((void*)uni64(second ? bX1 : bX0), 0, __builtin_amdgcn_readfirstlane(second ? nX1 : nX0), 0x00020000);
-    };
-    auto sw_slab_c = [&]() __attribute__((always_inline)) {
-        const bool second = cur_c >= p.c0;
-        sl_cb = (unsigned)(second ? p.c1 : p.c0) * 2u;
-        sl_uni = (unsigned)(cur_tpx * (int)sl_cb + (second ? cur_c - p.c0 : cur_c) * 2) + lcb;
-    };
-    auto sw_slab = [&](bool more) __attribute__((always_inline)) { sw_slab_a(more); sw_slab_b(); sw_slab_c(); };
     auto sw_piece = [&](int idx) __attribute__((always_inline)) {
         unsigned char* sw_ = smem + i_stage * STAGE;
         if (idx < WJ) {
-            const unsigned vo = (woff[idx] + sl_kb) | sl_dead;       // (an OOB row keeps bit 31 through the addition: sl_kb < 2^31)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(sl_rW, (lds_void*)(sw_ + (wave + NW * idx) * 1024), 16, vo, 0, 0, 0);
+            const unsigned vo = woff[idx] + sl_kb;                   // (an OOB row keeps bit 31 through the addition: sl_kb < 2^31)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(dW, (lds_void*)(sw_ + (wave + NW * idx) * 1024), 16, vo, 0, 0, 0);
         } else {
             const int j = idx - WJ;
             unsigned char* sx_ = sw_ + BC * 128;
             // branch-free: an invalid tap ORs bit 31 into the offset (the INVERTED mask shifted so that the tap's bit is bit 31), beyond every num_records
-            const unsigned inval = (xinv[j] << (31u - sl_tap)) & OOB;
-            const unsigned vo = ((unsigned)__mul24((int)xpx[j], (int)sl_cb) + sl_uni) | inval | sl_dead;
+            const unsigned inval = (xinv[j] << sl_sh) & OOB;
+            const unsigned vo = ((unsigned)__mul24((int)xpx[j], (int)sl_cb) + sl_uni) | inval;
             __builtin_amdgcn_raw_ptr_buffer_load_lds(sl_rX, (lds_void*)(sx_ + (wave + NW * j) * 1024), 16, vo, 0, 0, 0);
         }
     };
     auto sw_end = [&]() __attribute__((always_inline)) {
-        advance_cursor();
         i_stage ^= 1;
         ++i_kt;
     };
@@ -480,7 +505,7 @@ __global__ void __launch_bounds__(256, 1) conv_dma_w4_kernel(const ConvArgs p) {
             }
     };
     bool more = true;                                    // the slab whose pieces go out in the next scaled phase exists (wave-uniform)
-    auto prep = [&]() __attribute__((always_inline)) { more = sw_begin(); sw_slab(more); };
+    auto prep = [&]() __attribute__((always_inline)) { more = sw_begin(); sw_fetch(); sw_slab(); };
     auto f16_part = [&](unsigned so) __attribute__((always_inline)) {   // 32 f16 MFMAs of slab s; its fp8-side reads and conversions between them
         const unsigned aa = pa0 + so, a8a = pa8 + so, ba = pb0 + so + BC * 128u;
 #pragma unroll
@@ -502,7 +527,7 @@ __global__ void __launch_bounds__(256, 1) conv_dma_w4_kernel(const ConvArgs p) {
                 W4_MFMA_F16_HOT_P(acc[fa][fb], a[k2][fa], bh[k2][fb], cvp);
                 const int g = i - 1, kk = g / (2 * FB), f = (g >> 1) % FB, d = g & 1;
                 b8[f][2 * kk + d] = cvp;
-            } else if (W4_PREP_IN_F16 && i > FA * FB && i <= FA * FB + 5) {
+            } else if (W4_PREP_IN_F16 && (i == FA * FB + 1 || i == FA * FB + 5)) {
                 W4_MFMA_F16(acc[fa][fb], a[k2][fa], bh[k2][fb]);       // behind a book-keeping part (control flow joins in front of it): padded
             } else {
                 W4_MFMA_F16_HOT(acc[fa][fb], a[k2][fa], bh[k2][fb]);
@@ -534,15 +559,13 @@ __global__ void __launch_bounds__(256, 1) conv_dma_w4_kernel(const ConvArgs p) {
         // the second k-step is 16 MFMAs with nothing else to issue: the slab stream's scalar book-keeping — cursor advance of the slab whose pieces went out in this
         // iteration, then the next slab's address parts (a tile crossing's set-up included: a large block, once per tile) — goes behind its first MFMAs, one part each
         auto fence = [&](auto&& f) __attribute__((always_inline)) { __builtin_amdgcn_sched_barrier(0); f(); __builtin_amdgcn_sched_barrier(0); };
-        if (W4_PREP_IN_F16) fence([&]() __attribute__((always_inline)) { if (more) sw_end(); });
+        if (W4_PREP_IN_F16) fence([&]() __attribute__((always_inline)) { if (more) sw_end(); more = sw_begin(); sw_fetch(); });
         step(FA * FB + 1);
-        if (W4_PREP_IN_F16) fence([&]() __attribute__((always_inline)) { more = sw_begin(); });
         step(FA * FB + 2);
-        if (W4_PREP_IN_F16) fence([&]() __attribute__((always_inline)) { sw_slab_a(more); });
         step(FA * FB + 3);
-        if (W4_PREP_IN_F16) fence([&]() __attribute__((always_inline)) { sw_slab_b(); });
         step(FA * FB + 4);
-        if (W4_PREP_IN_F16) fence([&]() __attribute__((always_inline)) { sw_slab_c(); });
+        if (W4_PREP_IN_F16) fence([&]() __attribute__((always_inline)) { sw_slab(); });
+        if constexpr (W4_STAMPS == 1) { if (ph_crossed) { ph_stamp(7); ph_crossed = false; } }      // slot 7: MFMAs 16-20 + book-keeping of the iterations that cross tiles
         ph_stamp(3);
 #pragma unroll
         for (int i = FA * FB + 5; i < NM; ++i) step(i);

@@ -939,7 +939,9 @@ static int launch_dma_id(int id, const ConvArgs& a, hipStream_t st) {
             case 13: return launch_dma_cfg<64, 512, 1, 8, 2, 32, 0, true, true, true, true>(a, st);           // id 5, same
             case 15: return launch_dma_cfg<256, 256, 2, 4, 2, 32, 0, true, false, false, true, true>(a, st);       // id 6 with the slab loop software-pipelined across the barrier (SWP)
             case 9: return launch_dma_cfg<128, 512, 1, 8, 2, 32, 0, true, false, false, true, true>(a, st);        // id 8, same
-            case 16: return launch_conv_dma_w4(a, st);     // round 6: the 256x256 tile with ONE wave per SIMD (4 waves x 128x128, accumulators in a[0:255]): conv_dma_w4.hip
+            case 16:                                       // round 6: the 256x256 tile with ONE wave per SIMD (4 waves x 128x128, accumulators in a[0:255]): conv_dma_w4.hip
+                if (a.ktiles > 512) return launch_conv_dma(a, st, 15);   // (its slab table holds 512 k-slabs per tile: cin * taps <= 16384 halves; same bytes from id 15)
+                return launch_conv_dma_w4(a, st);
             case 14: {                  // DIAGNOSTIC (wrong results): id 11 with per-phase cycle sums written over the output (tools/slab_phases.py)
                 static const bool allow = [] { const char* e = getenv("MNET_ALLOW_DIAGNOSTIC_KERNELS"); return e && atoi(e) != 0; }();
                 if (!allow) return mnet_fail(MNET_E_ARG, "conv: fp16+8 LDS-DMA id 14 is a diagnostic build with wrong results (set MNET_ALLOW_DIAGNOSTIC_KERNELS=1 to use it)");
@@ -1028,7 +1030,9 @@ int conv_dma_pick(const ConvArgs& a) {
     if (a.split == 2) {
         // A/B knobs.  id 15 (round 4) = id 6 with the slab loop software-pipelined across the barrier: +0.5 ... +3.8 % over id 11 (= id 6 with the LDS reads
         // placed by scheduling hints) on the four shapes that carry the step, +1.2 % end to end, same bytes (profiles/r4g_*)
-        static const int env_mx_256 = [] { const char* e = getenv("MNET_MX_CFG256"); return e ? atoi(e) : 15; }();
+        // id 16 (round 6) = the same tile with ONE wave per SIMD (conv_dma_w4.hip: 4 waves x 128x128 outputs, accumulators in a[0:255]): +1.3 ... +2.5 % over id 15 on the
+        // shapes that carry the step at a 2-5 % higher shader clock for the same package power, same bytes (profiles/r6i_*); it writes GroupNorm sums itself
+        static const int env_mx_256 = [] { const char* e = getenv("MNET_MX_CFG256"); return e ? atoi(e) : 16; }();
         static const int env_mx_128 = [] { const char* e = getenv("MNET_MX_CFG128"); return e ? atoi(e) : 8; }();
         // (launches that write GroupNorm partial sums: id 15 runs its SGN build, conv_dma_swp_gn.hip; the software-pipelined 128x512 tile has no such build → its lock-step form 8)
         static const int env_gn_lockstep = [] { const char* e = getenv("MNET_GN_LOCKSTEP"); return e ? atoi(e) : 0; }();     // A/B knob: 1 = round-5's first form (id 15 → 11)

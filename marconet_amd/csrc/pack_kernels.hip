@@ -73,7 +73,7 @@ __global__ void __launch_bounds__(256) pack_weights_mx_kernel(const float* __res
     if ((t & 63) == 0) red[t >> 6] = m;
     __syncthreads();
     m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
-    const int e8 = min(254, max(11, hm_e8_of(m)));
+    const int e8 = min(254, max(11, hm_e8_raw(m)));
     const float inv_hi = __builtin_bit_cast(float, (unsigned)(254 - e8) << 23);         // 1 / s
     unsigned char* row = dst + (size_t)o * K * 4;
     for (int ch = t; ch < K / 8; ch += 256) {

@@ -5,7 +5,7 @@ One logical element = 4 bytes, blocked per 32 channels exactly like the split-ha
 
   activations   bytes 0-63    hi = f16(v), channels 0..31
                 bytes 64-95   lo8 = e4m3(lo * 2^11 / s), lo = v - hi, channel order PERM (0-7, 16-23 | 8-15, 24-31)
-                byte  96      E = E8M0 exponent of the block scale s = 2^(E - 127) = 2^(floor(log2 max|hi|) - 7)
+                byte  96      E = E8M0 exponent of the block scale s = 2^(E - 127) = 2^(max(floor(log2 max|hi|), -15) - 7); 0 for an all-zero block
                 bytes 97-127  zero
   conv weights  bytes 0-63    hi = f16(256 W)
                 bytes 64-79 lo8 of channels 0-7,16-23 | 80-95 hi8 of the same | 96-111 lo8 of 8-15,24-31 | 112-127 hi8 of the same
@@ -30,7 +30,10 @@ def _floor_log2(m):
 def block_e8(hi):
     """hi [..., 32] fp32 (values of halves) -> int32 [..., 1]: E8M0 byte of s = 2^(floor(log2 max|hi|) - 7)"""
     m = hi.abs().amax(-1, keepdim=True)
-    return (_floor_log2(m) - 7 + 127).clamp(0, 254).to(torch.int32)
+    # a non-zero block's exponent is floored at 127 - 15 - 7 = 105: below that the hi halves are fp16 subnormals and the scaled residual would leave e4m3's range
+    # (the device conversions return NaN there, not the saturated byte — csrc/common.h::hm_e8_of); an all-zero block keeps 0
+    e = _floor_log2(m) - 7 + 127
+    return torch.where(m > 0, e.clamp(105, 254), torch.zeros_like(e)).to(torch.int32)
 
 
 def _e4m3(v):

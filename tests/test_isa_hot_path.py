@@ -36,3 +36,40 @@ def test_dominant_tile_has_no_scratch_access_in_its_slab_loop(tmp_path):
     assert "ELb1ELb1EEv8ConvArgs" in r.stdout and "scratch accesses on the hot path: 0" in r.stdout and r.returncode == 0, r.stdout + r.stderr
     flag = open(os.path.join(ROOT, "marconet_amd", "csrc", "build.sh")).read()
     assert "conv_dma_swp_gn) echo \"-mllvm -greedy-reverse-local-assignment=1\"" in flag, "build.sh must compile conv_dma_swp_gn.hip with the flag this test checks"
+
+
+@pytest.mark.skipif(not (os.path.exists(HIPCC) or shutil.which("hipcc")), reason="needs hipcc")
+def test_one_wave_per_simd_tile_isa(tmp_path):
+    """round 6, conv_dma_w4.hip (fp16+8 id 16, AUTO for cout >= 256): its MFMAs are `asm volatile` statements with the accumulators in a[0:255] — hipcc neither
+    pads their hazards nor may it touch the accumulator file itself.  On the built ISA: 256 AGPRs allocated; no compiler v_accvgpr_write / _mov (a lazy copy of a
+    zeroed block in front of an unpadded MFMA corrupted register 0 of every block in round 6); no VALU write of an MFMA operand inside its two wait states
+    (tools/isa_mfma_hazards.py); no scratch access between the slab barrier and the loop's back edge outside the once-per-tile blocks."""
+    import re
+    asm = str(tmp_path / "conv_dma_w4.s")
+    cc = HIPCC if os.path.exists(HIPCC) else shutil.which("hipcc")
+    r = subprocess.run([cc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-S", "--cuda-device-only",
+                        os.path.join(ROOT, "marconet_amd", "csrc", "conv_dma_w4.hip"), "-o", asm], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    s = open(asm).read()
+    assert re.search(r"\.agpr_count:\s+256", s), "the 16 accumulator blocks must occupy a[0:255]"
+    assert int(re.search(r"\.vgpr_count:\s+(\d+)", s).group(1)) == 512
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "isa_mfma_hazards.py"), asm], capture_output=True, text=True, timeout=120)
+    print(r.stdout)
+    assert r.returncode == 0 and "0 finding(s)" in r.stdout, r.stdout + r.stderr
+    # the slab loop: from the LAST s_barrier (the loop's, after the peeled first iteration) to the branch back to its header; scratch accesses are tolerated only in
+    # blocks the ordinary slab branches around (the tile-closing epilogue, the tile crossing's set-up): every one of them must sit behind a forward branch that skips
+    # more than 200 lines
+    body = s[s.index("conv_dma_w4_kernel"):].split("\n")
+    bar = max(i for i, l in enumerate(body) if l.strip() == "s_barrier")
+    hdr = max(i for i in range(bar) if re.match(r"^\.LBB\d+_\d+:", body[i]))
+    label = body[hdr].split(":")[0]
+    back = max(i for i, l in enumerate(body) if re.search(r"s_c?branch\w*\s+" + re.escape(label) + r"\s*$", l.strip()))
+    labels = {m.group(1): i for i, l in enumerate(body) for m in [re.match(r"^(\.LBB\d+_\d+):", l)] if m}
+    skipped = set()
+    for i in range(hdr, back):
+        m = re.search(r"s_cbranch_\w+\s+(\.LBB\d+_\d+)", body[i])
+        if m and m.group(1) in labels and i + 200 < labels[m.group(1)] <= back + 5000:
+            skipped.update(range(i, labels[m.group(1)]))
+    hot = [(i, body[i].strip()) for i in range(hdr, back) if "scratch_" in body[i] and i not in skipped]
+    print("slab loop lines %d-%d, %d skipped as once-per-tile, hot scratch accesses: %d" % (hdr, back, len(skipped), len(hot)))
+    assert not hot, hot[:8]

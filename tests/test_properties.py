@@ -27,10 +27,10 @@ def test_fp16p8_activation_round_trip_properties(seed, log_scale, blocks, sparsi
     bb = b.reshape(5, blocks, 128)
     assert int(bb[..., 97:].max()) == 0
     assert torch.equal(y[0, :32], torch.zeros(32))
-    # scale byte = floor(log2 max|hi|) - 7 + 127 (clamped at 0), from the HI halves
+    # scale byte = max(floor(log2 max|hi|), -15) - 7 + 127 for a non-zero block (the floor: round 6, fp16-subnormal blocks), 0 for an all-zero one; from the HI halves
     hi = x.reshape(5, blocks, 32).to(torch.float16).float()
     m = hi.abs().amax(-1)
-    exp = torch.where(m > 0, torch.floor(torch.log2(m.double())).float() - 7 + 127, torch.zeros_like(m)).clamp(0, 254)
+    exp = torch.where(m > 0, (torch.floor(torch.log2(m.double())).float() - 7 + 127).clamp(105, 254), torch.zeros_like(m))
     assert torch.equal(bb[..., 96].float(), exp)
     # error bound: hi carries 11 significant bits of each value; the lo byte adds 4 more bits of the BLOCK's scale:
     # |v - decode| <= 2^-16 * 2^floor(log2 max|hi|) (half an e4m3 ulp at the top binade of lo) wherever fp16 itself is normal

@@ -58,7 +58,10 @@ def main():
     for k, nm in enumerate(NAMES):
         v = r[:, 3 + k] / slabs
         print("  %-62s %7.0f cycles (%4.1f %%)   by wave: %s" % (nm, v.mean(), 100 * v.mean() / tot.mean(), " ".join("%6.0f" % v[wave_id == j].mean() for j in range(4))))
-    if r[:, 10:16].sum() > 0:      # -DW4_STAMPS=2: sub-phases of the epilogue (phase 1 then holds only what is left outside them)
+    if r[:, 10].sum() > 0 and r[:, 11:16].sum() == 0:      # -DW4_STAMPS=1: slot 7 = the prep phase of the iterations that cross into the next tile (set-up included)
+        print("    prep phase of a tile-crossing iteration (5 MFMAs + the next tile's set-up): %.0f cycles per tile; of an ordinary iteration: %.0f cycles per slab"
+              % ((r[:, 10] / tiles.clamp(min=1)).mean(), (r[:, 6] / (slabs - tiles)).mean()))
+    if r[:, 11:16].sum() > 0:      # -DW4_STAMPS=2: sub-phases of the epilogue (phase 1 then holds only what is left outside them)
         sub = ["first step's parameter requests (per tile)", "accumulator reads + parameters + arithmetic + encode (8 steps)", "next step's requests (8 steps)",
                "LDS round 1 + stores (8 steps)", "LDS round 2 + stores (8 steps)", "GroupNorm fold + store (8 steps)"]
         for k, nm in enumerate(sub):
