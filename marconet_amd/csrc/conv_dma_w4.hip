@@ -84,23 +84,21 @@ static_assert(FA * FB == NDMA, "one DMA piece behind each scaled MFMA");
 // The one-float-per-lane form needs the 32 pixels of a fragment in ONE image (ho * wo % 32 == 0: every launch this tile is chosen for); otherwise (`rows_ok` false) the
 // out_scale / post_scale values are loaded per lane as in dma_epilogue_mx.
 // ACC::get(fa, px, q) takes a value out of the accumulator file where it is consumed.  `par`: this wave's parameter area (w4::PB bytes).
-template <bool GN, typename ACC, typename STAMP>
+// SC / RG: the launch has out_scale or post_scale / a residual or GroupNorm sums.  Four builds of the kernel (launch_conv_dma_w4 picks): a tile without them runs an
+// epilogue without their code, branches and kernel-argument reloads — measured on the bias + activation launches: 36 000 -> 29 000 cycles per tile (profiles/r6m_*).
+template <bool SC, bool RG, typename ACC, typename STAMP>
 __device__ __forceinline__ void w4_epilogue(const ConvArgs& p_, const ACC& acc, int co0, int pix0, int wc, int wp, int lane, unsigned char* xpose, unsigned char* par, STAMP&& stamp) {
     using namespace w4;
     constexpr int NPX = FB, NB = FA / 2, NS = NPX * NB;
     const int h = lane >> 5;
-#if defined(W4_EPI_PLAIN) && W4_EPI_PLAIN      // EXPERIMENT (wrong for launches with scales / residual / sums): what a bias + activation only epilogue costs
-    ConvArgs p = p_;
-    p.out_scale = nullptr; p.post_scale = nullptr; p.res = nullptr;
-#else
+    constexpr bool GN = RG;
     const ConvArgs& p = p_;
-#endif
+    const float* const p_out_scale = SC ? p.out_scale : nullptr;
+    const float* const p_post_scale = SC ? p.post_scale : nullptr;
+    const void* const p_res = RG ? p.res : nullptr;
     const int last_pix = p.npix - 1;
     float* gnp = nullptr;
     if constexpr (GN) gnp = kernarg_gn_partial();
-#if defined(W4_EPI_PLAIN) && W4_EPI_PLAIN
-    gnp = nullptr;
-#endif
     const bool rows_ok = (p.howo & 31) == 0;                               // (wave-uniform)
     int cob[NB], co[NB], co_l[NB];
 #pragma unroll
@@ -116,7 +114,7 @@ __device__ __forceinline__ void w4_epilogue(const ConvArgs& p_, const ACC& acc, 
 #pragma unroll
         for (int b = 0; b < NB; ++b) par_f[b * 64 + lane] = p.bias[min(cob[b] + lane, p.cout - 1)];
     }
-    struct Step { float osc1, psc1; u32x4 rh[4], rl[2]; unsigned re8; int pixb, pix, n_img; };
+    struct Step { float osc1, psc1; u32x4 rh[4], rl[2]; unsigned re8; int pixb, pix, n_img, vw; };
     auto request = [&](int t, Step& S) __attribute__((always_inline)) {     // addresses + parameter loads of step t (no use of the values here)
         const int px = t / NB, b = t % NB;
         S.pixb = pix0 + wp * (BP / WP) + px * 32;                           // first pixel of this wave's 32
@@ -126,12 +124,13 @@ __device__ __forceinline__ void w4_epilogue(const ConvArgs& p_, const ACC& acc, 
         if (rows_ok) {                                                      // the fragment's image is wave-uniform: one float of the 64-channel window per lane
             const int img = p2 ? min(S.pixb, last_pix) >> p.howo_shift : min(S.pixb, last_pix) / p.howo;
             const size_t row = (size_t)img * p.cout + min(cob[b] + lane, p.cout - 1);
-            if (p.out_scale) S.osc1 = p.out_scale[row];
-            if (p.post_scale) S.psc1 = p.post_scale[row];
+            if (p_out_scale) S.osc1 = p_out_scale[row];
+            if (p_post_scale) S.psc1 = p_post_scale[row];
         }
-        if (p.res && S.pix < p.npix) {
+        if (GN && gnp && p.valid_w) S.vw = p.valid_w[S.n_img];             // (the GroupNorm sums' column bound: requested with the rest, not behind the step's stores)
+        if (p_res && S.pix < p.npix) {
             const int rpix = p.res_mod > 0 ? S.pix % p.res_mod : S.pix;
-            const unsigned char* rb = reinterpret_cast<const unsigned char*>(p.res) + (size_t)rpix * p.cout * 4 + (co_l[b] >> 5) * 128;
+            const unsigned char* rb = reinterpret_cast<const unsigned char*>(p_res) + (size_t)rpix * p.cout * 4 + (co_l[b] >> 5) * 128;
 #pragma unroll
             for (int c = 0; c < 4; ++c) S.rh[c] = ldg16(rb + c * 16);
             S.rl[0] = ldg16(rb + 64); S.rl[1] = ldg16(rb + 80);           // lo bytes of chunks (0, 2) | (1, 3)
@@ -155,8 +154,8 @@ __device__ __forceinline__ void w4_epilogue(const ConvArgs& p_, const ACC& acc, 
         const int pixb = cur.pixb, pix = cur.pix, n_img = cur.n_img;
         float* const stepbuf = par_f + NB * 64 + (t & 1) * 128;
         if (rows_ok) {                                                      // this step's scale windows → LDS (read back below, per half)
-            if (p.out_scale) stepbuf[lane] = cur.osc1;
-            if (p.post_scale) stepbuf[64 + lane] = cur.psc1;
+            if (p_out_scale) stepbuf[lane] = cur.osc1;
+            if (p_post_scale) stepbuf[64 + lane] = cur.psc1;
         }
         float v[32];
 #pragma unroll
@@ -173,13 +172,13 @@ __device__ __forceinline__ void w4_epilogue(const ConvArgs& p_, const ACC& acc, 
                 for (int q = 0; q < 32; q += 4) { const f32x4 s4 = *reinterpret_cast<const f32x4*>(glob32 + q); v[q] *= s4[0]; v[q + 1] *= s4[1]; v[q + 2] *= s4[2]; v[q + 3] *= s4[3]; }
             }
         };
-        if (p.out_scale) scale32(stepbuf + 32 * h, p.out_scale + (size_t)n_img * p.cout + co_l[b]);
+        if (p_out_scale) scale32(stepbuf + 32 * h, p_out_scale + (size_t)n_img * p.cout + co_l[b]);
         if (p.bias) {
             const float* bp = par_f + b * 64 + 32 * h;
 #pragma unroll
             for (int q = 0; q < 32; q += 4) { const f32x4 b4 = *reinterpret_cast<const f32x4*>(bp + q); v[q] += b4[0]; v[q + 1] += b4[1]; v[q + 2] += b4[2]; v[q + 3] += b4[3]; }
         }
-        if (p.res && pix < p.npix) {
+        if (p_res && pix < p.npix) {
             const float sl = hm_lo_scale((int)cur.re8);
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
@@ -190,8 +189,16 @@ __device__ __forceinline__ void w4_epilogue(const ConvArgs& p_, const ACC& acc, 
                 for (int q = 0; q < 8; ++q) v[c * 8 + q] += (float)h8[q] + l[q];
             }
         }
-        act_apply_vec<32, true>(v, p.act);
-        if (p.post_scale) scale32(stepbuf + 64 + 32 * h, p.post_scale + (size_t)n_img * p.cout + co_l[b]);
+        // (LeakyReLU as max(v, 0.2 v): one multiply + one max instead of compare / multiply / select — the same value for every input: 0.2 v > v exactly when v < 0,
+        //  a NaN stays a NaN, -inf stays -inf; ReLU keeps act_apply_vec's form, whose relu(-inf) = NaN is wanted)
+        if (p.act == MNET_ACT_LRELU || p.act == MNET_ACT_LRELU_SQRT2) {
+            const float post = p.act == MNET_ACT_LRELU_SQRT2 ? 1.41421356237309515f : 1.f;
+#pragma unroll
+            for (int q = 0; q < 32; ++q) v[q] = fmaxf(v[q], v[q] * 0.2f) * post;
+        } else {
+            act_apply_vec<32, true>(v, p.act);
+        }
+        if (p_post_scale) scale32(stepbuf + 64 + 32 * h, p_post_scale + (size_t)n_img * p.cout + co_l[b]);
         // GroupNorm statistics of this output, part 1 (see dma_epilogue_mx): two fp32 sums per lane over its 32 channels of ONE group
         float gs1 = 0.f, gs2 = 0.f;
         if (GN && gnp) {
@@ -208,7 +215,7 @@ __device__ __forceinline__ void w4_epilogue(const ConvArgs& p_, const ACC& acc, 
         const int e8 = hm_e8_of(m);
         u32x2 lo[4];
 #pragma unroll
-        for (int c = 0; c < 4; ++c) lo[c] = hm_encode_lo_ref(v + c * 8, hh[c], e8);
+        for (int c = 0; c < 4; ++c) lo[c] = hm_encode_lo(v + c * 8, hh[c], e8);      // (the mixed-precision VALU form of the streaming kernels: the same bytes, a quarter fewer instructions — this epilogue IS instruction-bound)
         stamp(8);
         // the NEXT step's parameters are requested here — in front of this step's stores on the vmcnt counter
         Step nxt = cur;
@@ -255,7 +262,7 @@ __device__ __forceinline__ void w4_epilogue(const ConvArgs& p_, const ACC& acc, 
                 bool ok = pix < p.npix && co[b] < p.cout;
                 if (p.valid_w) {
                     const int ow = p.wo_shift >= 0 ? (pix & (p.wo - 1)) : pix % p.wo;
-                    ok = ok && ow < p.valid_w[n_img];
+                    ok = ok && ow < cur.vw;
                 }
                 gs1 = ok ? gs1 : 0.f; gs2 = ok ? gs2 : 0.f;
 #pragma unroll
@@ -270,6 +277,7 @@ __device__ __forceinline__ void w4_epilogue(const ConvArgs& p_, const ACC& acc, 
     }
 }
 
+template <bool SC, bool RG>
 __global__ void __launch_bounds__(256, 1) conv_dma_w4_kernel(const ConvArgs p) {
     using namespace w4;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -509,31 +517,39 @@ __global__ void __launch_bounds__(256, 1) conv_dma_w4_kernel(const ConvArgs p) {
     auto f16_part = [&](unsigned so) __attribute__((always_inline)) {   // 32 f16 MFMAs of slab s; its fp8-side reads and conversions between them
         const unsigned aa = pa0 + so, a8a = pa8 + so, ba = pb0 + so + BC * 128u;
 #pragma unroll
-        for (int f = 0; f < FB; ++f) bh[1][f] = *reinterpret_cast<const u32x4*>(smem + ((ba ^ 32u) + f * 4096u));         // chunk 2 + h
-#pragma unroll
-        for (int f = 0; f < FB; ++f) {
-            eb[f] = ebn[f];
-            const u32x4 lo8 = *reinterpret_cast<const u32x4*>(smem + ((ba ^ 64u) + f * 4096u));                           // chunk 4 + h
-            b8[f][4] = (int)lo8[0]; b8[f][5] = (int)lo8[1]; b8[f][6] = (int)lo8[2]; b8[f][7] = (int)lo8[3];
-        }
+        for (int f = 0; f < FB; ++f) eb[f] = ebn[f];
         __builtin_amdgcn_sched_barrier(0);
         // behind MFMA i:  i < 2 FA: one fp8-side weight read (lo8 / hi8 chunk of fragment i / 2);  i < FA FB, last pixel fragment of a row: the second k-step's
         // weight fragment;  i < 4 FB: one x_hi8 conversion group (2 v_cvt_scalef32_pk_fp8_f16 of 16 channels' halves; first k-step first)
         constexpr int NM = 2 * FA * FB;
         int cvp = 0;                                     // the conversion result of the gap before (named by the next MFMA statement, then filed into b8)
+        // the 4 FB conversion groups (group g: k-step g / (2 FB), pixel fragment (g >> 1) % FB, dword g & 1) are dealt over the gaps so that none carries more than the ~5
+        // instructions a 32-cycle MFMA hides (MI355X_MICROARCH.md): the first k-step's 2 FB groups behind MFMAs 0 ... 2 FB - 1 (beside the fp8-side weight reads), the
+        // second k-step's behind MFMAs CG1 ... CG1 + 2 FB - 1 of the second k-step, which have nothing else to issue
+        constexpr int CG1 = FA * FB + 5;
+        auto group_of = [](int i) constexpr -> int { return i < 0 ? -1 : (i < 2 * FB ? i : (i >= CG1 && i < CG1 + 2 * FB ? 2 * FB + (i - CG1) : -1)); };
+        static_assert(CG1 + 2 * FB < 2 * FA * FB, "the last conversion group needs an MFMA statement behind it to name its result");
         auto step = [&](int i) __attribute__((always_inline)) {
             const int k2 = i / (FA * FB), fa = (i % (FA * FB)) / FB, fb = i % FB;
-            if (i >= 1 && i - 1 < 4 * FB) {
+            if (group_of(i - 1) >= 0) {
                 W4_MFMA_F16_HOT_P(acc[fa][fb], a[k2][fa], bh[k2][fb], cvp);
-                const int g = i - 1, kk = g / (2 * FB), f = (g >> 1) % FB, d = g & 1;
+                const int g = group_of(i - 1), kk = g / (2 * FB), f = (g >> 1) % FB, d = g & 1;
                 b8[f][2 * kk + d] = cvp;
             } else if (W4_PREP_IN_F16 && (i == FA * FB + 1 || i == FA * FB + 5)) {
                 W4_MFMA_F16(acc[fa][fb], a[k2][fa], bh[k2][fb]);       // behind a book-keeping part (control flow joins in front of it): padded
             } else {
                 W4_MFMA_F16_HOT(acc[fa][fb], a[k2][fa], bh[k2][fb]);
             }
-            if (i < 2 * FA || i < 4 * FB || (i < FA * FB && fb == FB - 1)) {
+            if (i < FA * FB || group_of(i) >= 0) {
                 __builtin_amdgcn_sched_barrier(0);
+                // (the second k-step's pixel fragments and the activations' lo bytes: behind MFMAs 2 FA ... 2 FA + 2 FB - 1, which carry nothing else — requested in front of
+                //  MFMA 0 they were 8 LDS reads with the matrix pipe idle)
+                if (i >= 2 * FA && i < 2 * FA + FB) bh[1][i - 2 * FA] = *reinterpret_cast<const u32x4*>(smem + ((ba ^ 32u) + (i - 2 * FA) * 4096u));          // chunk 2 + h
+                if (i >= 2 * FA + FB && i < 2 * FA + 2 * FB) {
+                    const int f = i - 2 * FA - FB;
+                    const u32x4 lo8 = *reinterpret_cast<const u32x4*>(smem + ((ba ^ 64u) + f * 4096u));                       // chunk 4 + h
+                    b8[f][4] = (int)lo8[0]; b8[f][5] = (int)lo8[1]; b8[f][6] = (int)lo8[2]; b8[f][7] = (int)lo8[3];
+                }
                 if (i < 2 * FA) {
                     const int f = i >> 1;
                     const u32x4 q = *reinterpret_cast<const u32x4*>(smem + (((i & 1) ? (a8a ^ 16u) : a8a) + f * 4096u));       // chunk 4 + 2 h / 5 + 2 h
@@ -542,8 +558,8 @@ __global__ void __launch_bounds__(256, 1) conv_dma_w4_kernel(const ConvArgs p) {
                 }
                 if (i < FA * FB && fb == FB - 1)
                     a[1][fa] = *reinterpret_cast<const u32x4*>(smem + ((aa ^ 32u) + fa * 4096u));                          // chunk 2 + h
-                if (i < 4 * FB) {
-                    const int kk = i / (2 * FB), f = (i >> 1) % FB, d = i & 1;
+                if (group_of(i) >= 0) {
+                    const int g = group_of(i), kk = g / (2 * FB), f = (g >> 1) % FB, d = g & 1;
                     const float sc = __builtin_bit_cast(float, (unsigned)ebn[f] << 23);
                     s16x2 r = bitcast<s16x2>(b8[f][2 * kk + d]);      // (the destination's stale bytes as the tied operand: both halves are overwritten, no zeroing move)
                     r = __builtin_amdgcn_cvt_scalef32_pk_fp8_f16(r, bitcast<f16x2>(bh[kk][f][2 * d]), sc, false);
@@ -587,7 +603,7 @@ __global__ void __launch_bounds__(256, 1) conv_dma_w4_kernel(const ConvArgs p) {
         tile_coords(v, co0, pix0);
         mfma_drain();
         // (W4_STAMPS == 2: slots 7-12 = per tile: first request | per step, summed: arithmetic + encode | next step's requests | LDS round + stores 1 | 2 | GroupNorm fold)
-        w4_epilogue<true>(p, AccFile{acc}, co0, pix0, wc, wp, lane, xpose, smem + STAGES * STAGE + NW * XB + wave * PB,
+        w4_epilogue<SC, RG>(p, AccFile{acc}, co0, pix0, wc, wp, lane, xpose, smem + STAGES * STAGE + NW * XB + wave * PB,
                           [&](int i) __attribute__((always_inline)) { if constexpr (W4_STAMPS == 2) ph_stamp(i); });
     };
 
@@ -656,13 +672,20 @@ __global__ void __launch_bounds__(256, 1) conv_dma_w4_kernel(const ConvArgs p) {
     }
 }
 
-int launch_conv_dma_w4(const ConvArgs& a, hipStream_t st) {
-    static thread_local DeviceOnce attr_once;
+template <bool SC, bool RG>
+static int launch_w4(const ConvArgs& b, int grid, hipStream_t st) {
+    static thread_local DeviceOnce attr_once;      // per instantiation, per thread, per device
     if (!attr_once.done()) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_dma_w4_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, w4::LDS);
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_dma_w4_kernel<SC, RG>), hipFuncAttributeMaxDynamicSharedMemorySize, w4::LDS);
         if (e != hipSuccess) return mnet_fail(MNET_E_LAUNCH, "hipFuncSetAttribute(dma_w4): %s", hipGetErrorString(e));
         attr_once.mark();
     }
+    hipLaunchKernelGGL((conv_dma_w4_kernel<SC, RG>), dim3((unsigned)grid), dim3(w4::NW * 64), w4::LDS, st, b);
+    MNET_LAUNCH_CHECK("conv_dma_w4_kernel");
+    return MNET_OK;
+}
+
+int launch_conv_dma_w4(const ConvArgs& a, hipStream_t st) {
     ConvArgs b = a;
     auto log2_or_minus1 = [](int v) { return v > 0 && (v & (v - 1)) == 0 ? __builtin_ctz((unsigned)v) : -1; };
     b.howo_shift = log2_or_minus1(a.howo); b.wo_shift = log2_or_minus1(a.wo);
@@ -673,7 +696,7 @@ int launch_conv_dma_w4(const ConvArgs& a, hipStream_t st) {
     const int lim = dma_grid_limit();
     static const bool env_one_tile = [] { const char* e = getenv("MNET_DMA_ONE_TILE"); return e && atoi(e) != 0; }();
     if (grid > lim && !a.one_tile_per_wg && !env_one_tile) grid = lim & ~7;
-    hipLaunchKernelGGL(conv_dma_w4_kernel, dim3((unsigned)grid), dim3(w4::NW * 64), w4::LDS, st, b);
-    MNET_LAUNCH_CHECK("conv_dma_w4_kernel");
-    return MNET_OK;
+    const bool sc = a.out_scale || a.post_scale, rg = a.res || a.gn_partial;
+    if (sc) return rg ? launch_w4<true, true>(b, grid, st) : launch_w4<true, false>(b, grid, st);
+    return rg ? launch_w4<false, true>(b, grid, st) : launch_w4<false, false>(b, grid, st);
 }

@@ -32,10 +32,43 @@ def operands(line):
     return [o.strip() for o in ops]
 
 
+def hot_scratch(body):
+    """scratch accesses between the slab loop's barrier-carrying header and its back edge that an ordinary slab executes: those NOT behind a forward branch that skips
+    more than 200 lines (the tile-closing epilogue and the tile crossing's set-up are such blocks)"""
+    bar = max(i for i, l in enumerate(body) if l.strip() == "s_barrier")
+    hdr = max(i for i in range(bar) if re.match(r"^\.LBB\d+_\d+:", body[i]))
+    label = body[hdr].split(":")[0]
+    back = max(i for i, l in enumerate(body) if re.search(r"s_c?branch\w*\s+" + re.escape(label) + r"\s*$", l.strip()))
+    labels = {m.group(1): i for i, l in enumerate(body) for m in [re.match(r"^(\.LBB\d+_\d+):", l)] if m}
+    skipped = set()
+    for i in range(hdr, back):
+        m = re.search(r"s_cbranch_\w+\s+(\.LBB\d+_\d+)", body[i])
+        if m and m.group(1) in labels and i + 200 < labels[m.group(1)]:
+            skipped.update(range(i, labels[m.group(1)]))
+    def hot(l):
+        t = l.strip()
+        return "scratch_" in t or re.match(r"^v_accvgpr_(write|mov)", t)
+    asm_lines, ia = set(), False
+    for i, l in enumerate(body):
+        if ";;#ASMSTART" in l:
+            ia = True
+        elif ";;#ASMEND" in l:
+            ia = False
+        elif ia:
+            asm_lines.add(i)
+    return hdr, back, [(i, body[i].strip()) for i in range(hdr, back) if hot(body[i]) and i not in skipped and i not in asm_lines]
+
+
 def main():
     s = open(sys.argv[1]).read()
     name = sys.argv[2] if len(sys.argv) > 2 else "conv_dma_w4_kernel"
-    m = re.search(r"^(_Z\w*%s\w*):" % name, s, re.M)
+    rc = 0
+    for m in re.finditer(r"^(_Z\w*%s\w*):" % name, s, re.M):
+        rc |= check(s, m)
+    return rc
+
+
+def check(s, m):
     i = m.start()
     body = s[i:s.index(".Lfunc_end", i)].split("\n")
     instr = []                                      # (kind, text, in_asm): kind = 'i' instruction, 'l' label
@@ -53,12 +86,13 @@ def main():
                 instr.append(("l", t, in_asm))
             continue
         instr.append(("i", t, in_asm))
-    findings, n_mfma = [], 0
+    findings, n_mfma, spill_traffic = [], 0, []
     for k, (kind, t, ia) in enumerate(instr):
         if kind != "i":
             continue
         if re.match(r"^v_accvgpr_(write|mov)", t) and not ia:
-            findings.append("COMPILER ACCUMULATOR TRAFFIC: %s" % t)
+            spill_traffic.append(t)        # hipcc parking a VGPR in an accumulator register whose block is dead (after the epilogue has read it): legal — the two-wait-state
+                                           # walk below still covers every MFMA behind such a write; reported, and a finding only on the slab loop's ordinary path (hot_scratch)
         if not t.startswith("v_mfma"):
             continue
         n_mfma += 1
@@ -82,7 +116,10 @@ def main():
                         findings.append("HAZARD %d wait state(s): `%s` writes an operand of `%s`" % (states, tt[:70], t[:90]))
                 states += 1
             j -= 1
-    print("%s: %d MFMAs checked, %d finding(s)" % (m.group(1), n_mfma, len(findings)))
+    hdr, back, hot = hot_scratch(body)
+    for i_, t_ in hot:
+        findings.append("HOT SCRATCH / ACCUMULATOR-FILE SPILL line %d of the slab loop (%d-%d): %s" % (i_, hdr, back, t_[:80]))
+    print("%s: %d MFMAs checked, %d compiler accumulator-file moves outside the hot path, %d finding(s)" % (m.group(1), n_mfma, len(spill_traffic), len(findings)))
     for f in findings[:40]:
         print("   ", f)
     return 1 if findings else 0
