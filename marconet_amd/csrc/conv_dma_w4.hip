@@ -35,6 +35,10 @@
 #ifndef W4_STAMPS
 #define W4_STAMPS 0
 #endif
+//   W4_ACT_FIRST (0)    A/B: the activation pieces (HBM / L2) behind the first 8 scaled MFMAs, the weight pieces (L2-resident) behind the last 8
+#ifndef W4_ACT_FIRST
+#define W4_ACT_FIRST 0
+#endif
 
 namespace w4 {
 constexpr int BC = 256, BP = 256, WC = 2, WP = 2, NW = 4;
@@ -508,7 +512,7 @@ __global__ void __launch_bounds__(256, 1) conv_dma_w4_kernel(const ConvArgs p) {
                 W4_MFMA_SC(acc[fa][fb], a8[fa], b8[fb], mx_sa[fa], eb[fb]);
                 __builtin_amdgcn_sched_barrier(0);
                 if (reads && i < FA + 2 * FB) front_read(so, i);
-                if (pieces) sw_piece(i);
+                if (pieces) sw_piece(W4_ACT_FIRST ? (i + WJ) % NDMA : i);
                 __builtin_amdgcn_sched_barrier(0);
             }
     };

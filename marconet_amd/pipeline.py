@@ -12,6 +12,7 @@ import torch
 
 from . import ops
 from .glyphs import GlyphTables
+from .networks import returned_image_precision
 from .packing import default_precision, new_tensor, torch_dtype
 
 
@@ -113,7 +114,8 @@ class MarconetPipeline:
             p64 = new_tensor((G, 64, 64, 256), gdt, lq.device)
             p32 = new_tensor((G, 32, 32, 512), gdt, lq.device)
             # a returned image is computed in the mode's arithmetic; a dropped one under ``prior_image_precision`` (see forward_batch)
-            img_prec = self._image_precision() if prior_images is None or self.prior_image_precision != "auto" else None
+            # (a RETURNED image in the fp16x2 mode: its image-only level in the three-product arithmetic, networks.returned_image_precision)
+            img_prec = self._image_precision() if prior_images is None or self.prior_image_precision != "auto" else returned_image_precision(self.precision)
             for s in range(0, G, self.glyph_chunk):
                 e = min(G, s + self.glyph_chunk)
                 if _NO_STYLE_DEDUPE:

@@ -74,7 +74,9 @@ def test_generator_priors_on_the_trained_like_regime(regime_pipes):
     from marconet_amd import synthetic
     styles, labels = synthetic.make_styles(91, 6), synthetic.make_labels(92, 6)
     ref = O.tspgan_forward(sdg, styles, labels)
-    for prec, bars in (("fp32", (1e-3, 1e-3, 1e-3)), ("fp16x3", (1e-3, 1e-3, 1e-3)), ("fp16x2", (1e-3, 2e-3, 2e-3))):
+    # (round 6: the fp16x2 bars are the north star's — 1e-3 absolute on the image, 1e-3 x max(1, |p|) on the priors; the image's own level runs in fp16x3 when the
+    #  image is returned: networks.returned_image_precision)
+    for prec, bars in (("fp32", (1e-3, 1e-3, 1e-3)), ("fp16x3", (1e-3, 1e-3, 1e-3)), ("fp16x2", (1e-3, 1e-3, 1e-3))):
         pipe.gan.set_precision(prec)
         out = pipe.gan(styles=styles.to(DEV), labels=labels.to(DEV), noise=None)
         errs = [(o.cpu() - r).abs().max().item() for o, r in zip(out, ref)]

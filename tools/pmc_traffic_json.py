@@ -21,15 +21,17 @@ def main():
         # template arguments: BC, BP, WC, WP, STAGES, MF, DBG = 0, X3, SPREAD, PIPE, MX, SWP, SGN (round 5: the software-pipelined tile built with the
         # GroupNorm-sum block, conv_dma_swp_gn.hip — the SAME tile id for bench.py, so its launches are folded into the "swp" entry)
         m = re.match(r"void conv_dma_kernel<(\d+), (\d+), (\d+), (\d+), (\d+), (\d+), 0(?:, (\w+))?(?:, (\w+))?(?:, (\w+))?(?:, (\w+))?(?:, (\w+))?(?:, (\w+))?>", lines[0])
-        if not m:
+        w4 = re.match(r"void conv_dma_w4_kernel<", lines[0])        # round 6: the one-wave-per-SIMD tile (four builds by epilogue features: ONE tile id for bench.py)
+        if not m and not w4:
             continue
-        x3, spread, pipe, mx, swp = (m.group(i) in ("true", "1") for i in (7, 8, 9, 10, 11))
+        if m:
+            x3, spread, pipe, mx, swp = (m.group(i) in ("true", "1") for i in (7, 8, 9, 10, 11))
         c = {}
         for l in lines[1:]:
             q = re.match(r"\s+(\S+)\s+mean/dispatch\s+([\d.]+)\s+dispatches (\d+)", l)
             if q:
                 c[q.group(1)] = (float(q.group(2)), int(q.group(3)))
-        key = ("conv_dma_kernel<%s,mx%s> f16x2" % (",".join(m.groups()[:6]), ",swp" if swp else (",pipe" if pipe else "")) if mx else
+        key = "conv_dma_w4_kernel f16x2" if w4 else ("conv_dma_kernel<%s,mx%s> f16x2" % (",".join(m.groups()[:6]), ",swp" if swp else (",pipe" if pipe else "")) if mx else
                "conv_dma_kernel<%s%s>%s" % (",".join(m.groups()[:6]), (",spread" if spread else "") + (",pipe" if pipe else ""), " f16x3" if x3 else ""))
         a = acc.setdefault(key, {})
         for name, (mean, n) in c.items():        # totals over the dispatches of every build that carries this key

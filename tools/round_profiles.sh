@@ -25,12 +25,15 @@ timeout 400 python bench.py --config mixed --steps 3 --precision "$PREC" > "$O/b
 stats "bench_mixed_b256_${PREC}" "rocprofv3 --kernel-trace --stats -- python bench.py --config mixed --steps 2 --cpu-images 0 --precision $PREC (configs[4]: widths 128..512)" -- --config mixed --steps 2 --cpu-images 0 --precision "$PREC"
 timeout 400 python bench.py --steps 3 --force-gather --cpu-images 0 --precision "$PREC" > "$O/bench_force_gather_${PREC}.json" 2> "$O/bench_force_gather.err"
 for p in fp16x2 fp16x3 fp16; do timeout 200 python tools/graph_latency.py 16 50 $p; done > "$O/graph_latency.txt" 2>&1
-timeout 400 python tools/tile_power_ab.py --seconds 5 --only x3:11,x2:6,x2:11,x2:15,f16:16 > "$O/tile_power_ab.txt" 2>&1
-( cd /tmp && timeout 300 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE --output-format csv -d "$O/pmc_tiles" -o pmc -- python "$R/tools/tile_power_ab.py" --launches 6 --only x3:11,x2:11,x2:15 ) > "$O/pmc_tiles.log" 2>&1
+timeout 400 python tools/tile_power_ab.py --seconds 5 --only x3:11,x2:6,x2:11,x2:15,x2:16,f16:16 > "$O/tile_power_ab.txt" 2>&1
+( cd /tmp && timeout 300 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE --output-format csv -d "$O/pmc_tiles" -o pmc -- python "$R/tools/tile_power_ab.py" --launches 6 --only x3:11,x2:11,x2:15,x2:16 ) > "$O/pmc_tiles.log" 2>&1
 python tools/pmc_summary.py "$O/pmc_tiles" "$O/pmc_tiles_x3_mf16_mf32_x2.txt" conv_dma > /dev/null
 # per-launch conv table of one step, per-phase cycles of the dominant tile (lock-step and software-pipelined form), micro-benchmarks
 timeout 400 python tools/profile_layers.py --batch 256 --glyphs 16 --precision "$PREC" --out "$O/conv_layers_b256_n16_${PREC}.txt" > /dev/null 2>&1
 { timeout 200 python tools/slab_phases.py; timeout 200 python tools/slab_phases.py --swp; timeout 200 python tools/slab_phases.py --swp --zeros; } 2>&1 | grep -v "Warn\|amdgpu.ids" > "$O/slab_phases.txt"
+# the one-wave-per-SIMD tile (id 16): phase stamps need the diagnostic build (tools/build_variant.sh w4_stamps conv_dma_w4 -DW4_STAMPS=1, built before the lease)
+[ -f tools/_build/w4_stamps/libmarconet_hip.so ] && { MARCONET_HIP_LIB=$R/tools/_build/w4_stamps/libmarconet_hip.so timeout 200 python tools/w4_phases.py; MARCONET_HIP_LIB=$R/tools/_build/w4_stamps/libmarconet_hip.so timeout 200 python tools/w4_phases.py --zeros;
+  MARCONET_HIP_LIB=$R/tools/_build/w4_stamps/libmarconet_hip.so timeout 200 python tools/w4_phases.py --shape 1024,64,64,512,256; } 2>&1 | grep -v "Warn\|amdgpu.ids" > "$O/w4_phases.txt"
 [ -x tools/_build/lds_dma_peak ] && timeout 120 tools/_build/lds_dma_peak > "$O/lds_dma_peak_microbench.txt" 2>&1
 [ -x tools/_build/mfma_slab ] && { timeout 120 tools/_build/mfma_slab z; timeout 120 tools/_build/mfma_slab; } > "$O/mfma_slab_microbench.txt" 2>&1
 rm -rf "$O"/prof_*/ "$O"/pmc/*/ "$O/pmc_tiles"/*/ 2>/dev/null      # raw traces are large; the summaries stay
