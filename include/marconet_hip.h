@@ -153,7 +153,10 @@ enum { MNET_CONV_ALGO_AUTO = 0, MNET_CONV_ALGO_REG_STAGED = 1, MNET_CONV_ALGO_LD
                                        *   id 16: 256x256 8w 2st (128x64 per wave) with both half slabs' operand fragments requested up front and the
                                        *          next slab's DMA pieces issued between the halves — AUTO's f16 choice for cout >= 256, >= 65536 pixels
                                        *   id 17: the same form of the 128x512 tile (64x128 per wave)
-                                       * same MFMA sequence as ids 0-6: identical bits */,
+                                       * same MFMA sequence as ids 0-6: identical bits.
+                                       *   MNET_F16M launches, id 16 (round 6): the 256x256 tile with ONE wave per SIMD — 4 waves x 128x128 outputs, the accumulators
+                                       *          in the accumulator register file (conv_dma_w4.hip) — AUTO's fp16+8 choice for cout >= 256, >= 65536 pixels; writes
+                                       *          mnet_conv_desc.gn_partial itself; same MFMA sequence per output as the fp16+8 ids 0-15: identical bytes */,
        MNET_CONV_ALGO_FLAG_ONE_TILE = 256 /* OR-ed in: LDS-DMA kernel launched with one workgroup per tile instead of its
                                             * persistent grid (A/B measurements only; same results) */,
        MNET_CONV_ALGO_FLAG_X1_CENTER = 512 /* OR-ed in (round 4): the SECOND source x1 contributes through the filter's CENTRE tap only —
