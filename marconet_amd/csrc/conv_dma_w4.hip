@@ -87,7 +87,7 @@ static_assert(FA * FB == NDMA, "one DMA piece behind each scaled MFMA");
 //   * the residual block of step t + 1 (7 loads per lane) is requested BEFORE the stores of step t, so the wait in front of step t + 1's arithmetic leaves those stores in flight.
 // The one-float-per-lane form needs the 32 pixels of a fragment in ONE image (ho * wo % 32 == 0: every launch this tile is chosen for); otherwise (`rows_ok` false) the
 // out_scale / post_scale values are loaded per lane as in dma_epilogue_mx.
-// ACC::get(fa, px, q) takes a value out of the accumulator file where it is consumed.  `par`: this wave's parameter area (w4::PB bytes).
+// ACC::block(fa, px) takes a block's 16 values out of the accumulator file where they are consumed.  `par`: this wave's parameter area (w4::PB bytes).
 // SC / RG: the launch has out_scale or post_scale / a residual or GroupNorm sums.  Four builds of the kernel (launch_conv_dma_w4 picks): a tile without them runs an
 // epilogue without their code, branches and kernel-argument reloads — measured on the bias + activation launches: 36 000 -> 29 000 cycles per tile (profiles/r6m_*).
 template <bool SC, bool RG, typename ACC, typename STAMP>
@@ -162,8 +162,11 @@ __device__ __forceinline__ void w4_epilogue(const ConvArgs& p_, const ACC& acc, 
             if (p_post_scale) stepbuf[64 + lane] = cur.psc1;
         }
         float v[32];
+        {
+            const f32x16 b0 = acc.block(2 * b, px), b1 = acc.block(2 * b + 1, px);      // out of the accumulator file HERE (see AccFile)
 #pragma unroll
-        for (int q = 0; q < 16; ++q) { v[q] = acc.get(2 * b, px, q) * MNET_SPLIT_WSCALE_INV; v[16 + q] = acc.get(2 * b + 1, px, q) * MNET_SPLIT_WSCALE_INV; }
+            for (int q = 0; q < 16; ++q) { v[q] = b0[q] * MNET_SPLIT_WSCALE_INV; v[16 + q] = b1[q] * MNET_SPLIT_WSCALE_INV; }
+        }
         // (two address spaces: an LDS-or-global pointer select would compile to flat loads, which wait on both counters)
         auto scale32 = [&](const float* lds32, const float* glob32) __attribute__((always_inline)) {
             if (rows_ok) {
@@ -592,14 +595,16 @@ __global__ void __launch_bounds__(256, 1) conv_dma_w4_kernel(const ConvArgs p) {
     };
     // the wait states a 16-pass MFMA's result needs before a VALU (v_accvgpr_read of the epilogue) may read it: hipcc pads nothing behind an asm statement
     auto mfma_drain = [&]() __attribute__((always_inline)) { asm volatile("s_nop 15\n\ts_nop 7" ::: "memory"); };
-    // the epilogue takes a block's 16 values out of the accumulator file WHERE IT CONSUMES THEM (asm volatile: not hoisted).  Left to the compiler the 256 reads are
-    // scheduled to the top of the epilogue — at one wave per SIMD its scheduler sees no reason to keep the pressure under 256 — and the allocator spills the slab loop.
+    // the epilogue takes a block's 16 values out of the accumulator file WHERE IT CONSUMES THEM.  Left to the compiler the 256 reads are scheduled to the top of the
+    // epilogue — at one wave per SIMD its scheduler sees no reason to keep the pressure under 256 — and the allocator spills the slab loop.
     struct AccFile {
         f32x16 (&r)[FA][FB];
-        __device__ __forceinline__ float get(int fa, int px, int q) const {
-            float v;
-            asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(v) : "a"(r[fa][px][q]));
-            return v;
+        // an empty asm statement that names the block as read-write: hipcc cannot read the block's registers above it (it "changes" there) nor move it above the MFMAs (both
+        // volatile), so the 16 v_accvgpr_read_b32 of the copy below are generated — and scheduled, without the boundary pads 32 one-register asm reads cost — where the step
+        // consumes them
+        __device__ __forceinline__ f32x16 block(int fa, int px) const {
+            asm volatile("" : "+a"(r[fa][px]));
+            return r[fa][px];
         }
     };
     auto epilogue = [&](int v) __attribute__((always_inline)) {

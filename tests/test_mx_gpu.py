@@ -688,3 +688,18 @@ def test_one_wave_per_simd_tile_groupnorm_sums(case):
         got.append((y.cpu().view(torch.uint8), part.cpu()))
     assert torch.isfinite(got[1][1]).all()
     assert torch.equal(got[0][0], got[1][0]) and torch.equal(got[0][1], got[1][1])
+
+
+def test_one_wave_per_simd_tile_scale_rows_of_maps_that_are_not_multiples_of_32_pixels():
+    """w4_epilogue stages out_scale / post_scale through the LDS one float per lane when a 32-pixel fragment lies in ONE image (ho * wo % 32 == 0); other maps take the
+    per-lane loads of dma_epilogue_mx — same bytes as the 8-wave tile either way (fragments straddling images, a pixel tail, ragged widths)"""
+    ops = _ops()
+    for (n, h, w) in ((20, 10, 10), (7, 12, 20), (9, 16, 16)):          # 100 / 240 / 256 pixels per image
+        cin, cout = 64, 256
+        x = _to_mx(_rnd((n, cin, h, w), 201))
+        wp = _pack_w(_rnd((cout, cin, 3, 3), 202, 1.0 / math.sqrt(cin * 9)))
+        osc, psc = (_rnd((n, cout), 203).abs() + 0.5).to(DEV), (_rnd((n, cout), 204).abs() + 0.5).to(DEV)
+        bias = _rnd((cout,), 205, 0.3).to(DEV)
+        vw = torch.tensor([w - (i % 3) for i in range(n)], dtype=torch.int32, device=DEV)
+        outs = [ops.conv2d(x, wp, cout, 3, 3, (1, 1), (1, 1), out_scale=osc, post_scale=psc, bias=bias, act=3, valid_w=vw, algo=_tile(i)).cpu().view(torch.uint8) for i in (6, W4)]
+        assert torch.equal(outs[0], outs[1]), (n, h, w)
