@@ -529,19 +529,20 @@ __global__ void __launch_bounds__(256, 1) conv_dma_w4_kernel(const ConvArgs p) {
         // behind MFMA i:  i < 2 FA: one fp8-side weight read (lo8 / hi8 chunk of fragment i / 2);  i < FA FB, last pixel fragment of a row: the second k-step's
         // weight fragment;  i < 4 FB: one x_hi8 conversion group (2 v_cvt_scalef32_pk_fp8_f16 of 16 channels' halves; first k-step first)
         constexpr int NM = 2 * FA * FB;
-        int cvp = 0;                                     // the conversion result of the gap before (named by the next MFMA statement, then filed into b8)
+        int cvq[2] = {0, 0};                             // conversion results in flight: the one of gap i is named by MFMA statement i + 2 (not i + 1: hipcc pads a wait state between a
+                                                         // VALU write and an asm statement that names the register — 16 s_nop per slab in gaps that are full), then filed into b8
         // the 4 FB conversion groups (group g: k-step g / (2 FB), pixel fragment (g >> 1) % FB, dword g & 1) are dealt over the gaps so that none carries more than the ~5
         // instructions a 32-cycle MFMA hides (MI355X_MICROARCH.md): the first k-step's 2 FB groups behind MFMAs 0 ... 2 FB - 1 (beside the fp8-side weight reads), the
         // second k-step's behind MFMAs CG1 ... CG1 + 2 FB - 1 of the second k-step, which have nothing else to issue
         constexpr int CG1 = FA * FB + 5;
         auto group_of = [](int i) constexpr -> int { return i < 0 ? -1 : (i < 2 * FB ? i : (i >= CG1 && i < CG1 + 2 * FB ? 2 * FB + (i - CG1) : -1)); };
-        static_assert(CG1 + 2 * FB < 2 * FA * FB, "the last conversion group needs an MFMA statement behind it to name its result");
+        static_assert(CG1 + 2 * FB + 1 < 2 * FA * FB, "the last conversion group needs an MFMA statement two gaps behind it to name its result");
         auto step = [&](int i) __attribute__((always_inline)) {
             const int k2 = i / (FA * FB), fa = (i % (FA * FB)) / FB, fb = i % FB;
-            if (group_of(i - 1) >= 0) {
-                W4_MFMA_F16_HOT_P(acc[fa][fb], a[k2][fa], bh[k2][fb], cvp);
-                const int g = group_of(i - 1), kk = g / (2 * FB), f = (g >> 1) % FB, d = g & 1;
-                b8[f][2 * kk + d] = cvp;
+            if (group_of(i - 2) >= 0) {
+                W4_MFMA_F16_HOT_P(acc[fa][fb], a[k2][fa], bh[k2][fb], cvq[i & 1]);
+                const int g = group_of(i - 2), kk = g / (2 * FB), f = (g >> 1) % FB, d = g & 1;
+                b8[f][2 * kk + d] = cvq[i & 1];
             } else if (W4_PREP_IN_F16 && (i == FA * FB + 1 || i == FA * FB + 5)) {
                 W4_MFMA_F16(acc[fa][fb], a[k2][fa], bh[k2][fb]);       // behind a book-keeping part (control flow joins in front of it): padded
             } else {
@@ -571,7 +572,7 @@ __global__ void __launch_bounds__(256, 1) conv_dma_w4_kernel(const ConvArgs p) {
                     s16x2 r = bitcast<s16x2>(b8[f][2 * kk + d]);      // (the destination's stale bytes as the tied operand: both halves are overwritten, no zeroing move)
                     r = __builtin_amdgcn_cvt_scalef32_pk_fp8_f16(r, bitcast<f16x2>(bh[kk][f][2 * d]), sc, false);
                     r = __builtin_amdgcn_cvt_scalef32_pk_fp8_f16(r, bitcast<f16x2>(bh[kk][f][2 * d + 1]), sc, true);
-                    cvp = bitcast<int>(r);                                 // filed into b8 behind the next MFMA statement, which names it (see W4_MFMA_F16_HOT_P)
+                    cvq[i & 1] = bitcast<int>(r);                          // filed into b8 behind MFMA statement i + 2, which names it (see W4_MFMA_F16_HOT_P)
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
