@@ -85,13 +85,16 @@ static_assert(FA * FB == NDMA, "one DMA piece behind each scaled MFMA");
 //     broadcast ds_read_b128 (lgkmcnt: not ordered behind the stores).  The bias window is fetched once per tile (it does not depend on the pixel fragment), the
 //     out_scale / post_scale windows (rows of the fragment's image) one step ahead;
 //   * the residual block of step t + 1 (7 loads per lane) is requested BEFORE the stores of step t, so the wait in front of step t + 1's arithmetic leaves those stores in flight.
-// The one-float-per-lane form needs the 32 pixels of a fragment in ONE image (ho * wo % 32 == 0: every launch this tile is chosen for); otherwise (`rows_ok` false) the
-// out_scale / post_scale values are loaded per lane as in dma_epilogue_mx.
+// The one-float-per-lane form needs the 32 pixels of a fragment in ONE image (ho * wo % 32 == 0) and the arithmetic has the identity / LeakyReLU arms only: the launcher
+// hands every other launch to the 8-wave tile.  Straight-line arithmetic (round 6, last pass): a bias the launch does not have is zeros, a scale vector it does not have is
+// ones, 2^-8 rides in the fma with the bias (or in out_scale) — every runtime branch in the step split hipcc's scheduling region and copied the 32 values at its join.
 // ACC::block(fa, px) takes a block's 16 values out of the accumulator file where they are consumed.  `par`: this wave's parameter area (w4::PB bytes).
 // SC / RG: the launch has out_scale or post_scale / a residual or GroupNorm sums.  Four builds of the kernel (launch_conv_dma_w4 picks): a tile without them runs an
 // epilogue without their code, branches and kernel-argument reloads — measured on the bias + activation launches: 36 000 -> 29 000 cycles per tile (profiles/r6m_*).
 template <bool SC, bool RG, typename ACC, typename STAMP>
 __device__ __forceinline__ void w4_epilogue(const ConvArgs& p_, const ACC& acc, int co0, int pix0, int wc, int wp, int lane, unsigned char* xpose, unsigned char* par, STAMP&& stamp) {
+#pragma clang fp contract(off)      // every product and sum rounded on its own, as in dma_epilogue_mx — whose runtime arms keep hipcc from fusing across them; in this straight-line
+                                    // form it fused scale * acc + bias into an fma
     using namespace w4;
     constexpr int NPX = FB, NB = FA / 2, NS = NPX * NB;
     const int h = lane >> 5;
@@ -103,7 +106,6 @@ __device__ __forceinline__ void w4_epilogue(const ConvArgs& p_, const ACC& acc, 
     const int last_pix = p.npix - 1;
     float* gnp = nullptr;
     if constexpr (GN) gnp = kernarg_gn_partial();
-    const bool rows_ok = (p.howo & 31) == 0;                               // (wave-uniform)
     int cob[NB], co[NB], co_l[NB];
 #pragma unroll
     for (int b = 0; b < NB; ++b) {
@@ -114,10 +116,8 @@ __device__ __forceinline__ void w4_epilogue(const ConvArgs& p_, const ACC& acc, 
     // LDS parameter area of this wave: [bias: NB x 64 floats][step buffer 0: out_scale 64 | post_scale 64 floats][step buffer 1].  A lane's own value of a 64-channel
     // window sits at float index `lane`; its half's 32 values are the 8 chunks at float index 32 h.  (channels >= cout: any in-range value — those blocks are not stored)
     float* const par_f = reinterpret_cast<float*>(par);
-    if (p.bias) {
 #pragma unroll
-        for (int b = 0; b < NB; ++b) par_f[b * 64 + lane] = p.bias[min(cob[b] + lane, p.cout - 1)];
-    }
+    for (int b = 0; b < NB; ++b) par_f[b * 64 + lane] = p.bias ? p.bias[min(cob[b] + lane, p.cout - 1)] : 0.f;      // (no bias: zeros — the add below is unconditional)
     struct Step { float osc1, psc1; u32x4 rh[4], rl[2]; unsigned re8; int pixb, pix, n_img, vw; };
     auto request = [&](int t, Step& S) __attribute__((always_inline)) {     // addresses + parameter loads of step t (no use of the values here)
         const int px = t / NB, b = t % NB;
@@ -125,10 +125,13 @@ __device__ __forceinline__ void w4_epilogue(const ConvArgs& p_, const ACC& acc, 
         S.pix = S.pixb + (lane & 31);
         const bool p2 = p.howo_shift >= 0;                                  // (wave-uniform) every map of this network: a shift instead of an integer division per lane and step
         S.n_img = p2 ? min(S.pix, last_pix) >> p.howo_shift : min(S.pix, last_pix) / p.howo;
-        if (rows_ok) {                                                      // the fragment's image is wave-uniform: one float of the 64-channel window per lane
+        if constexpr (SC) {                                                 // the fragment's image is wave-uniform (ho * wo % 32 == 0): one float of the 64-channel window per lane
             const int img = p2 ? min(S.pixb, last_pix) >> p.howo_shift : min(S.pixb, last_pix) / p.howo;
             const size_t row = (size_t)img * p.cout + min(cob[b] + lane, p.cout - 1);
-            if (p_out_scale) S.osc1 = p_out_scale[row];
+            // (a vector the launch does not have: ones — the multiplies below are unconditional.  2^-8 of the weight scale rides in out_scale: a power of two, the
+            //  product acc * (2^-8 s) is the once-rounded acc * 2^-8 * s of dma_epilogue_mx bit for bit)
+            S.osc1 = MNET_SPLIT_WSCALE_INV; S.psc1 = 1.f;
+            if (p_out_scale) S.osc1 = p_out_scale[row] * MNET_SPLIT_WSCALE_INV;
             if (p_post_scale) S.psc1 = p_post_scale[row];
         }
         if (GN && gnp && p.valid_w) S.vw = p.valid_w[S.n_img];             // (the GroupNorm sums' column bound: requested with the rest, not behind the step's stores)
@@ -155,35 +158,30 @@ __device__ __forceinline__ void w4_epilogue(const ConvArgs& p_, const ACC& acc, 
 #pragma unroll
     for (int t = 0; t < NS; ++t) {
         const int px = t / NB, b = t % NB;
-        const int pixb = cur.pixb, pix = cur.pix, n_img = cur.n_img;
+        const int pixb = cur.pixb, pix = cur.pix;
         float* const stepbuf = par_f + NB * 64 + (t & 1) * 128;
-        if (rows_ok) {                                                      // this step's scale windows → LDS (read back below, per half)
-            if (p_out_scale) stepbuf[lane] = cur.osc1;
-            if (p_post_scale) stepbuf[64 + lane] = cur.psc1;
+        if constexpr (SC) { stepbuf[lane] = cur.osc1; stepbuf[64 + lane] = cur.psc1; }      // this step's scale windows → LDS (read back below, per half)
+        typedef __attribute__((address_space(3))) const f32x4* lds_f32x4;
+        f32x4 bia[8];                                                       // this half's 32 bias values (8 broadcast reads, requested in front of the accumulator reads)
+        {
+            const lds_f32x4 b4 = (lds_f32x4)(par_f + b * 64 + 32 * h);
+#pragma unroll
+            for (int q = 0; q < 8; ++q) bia[q] = b4[q];
         }
         float v[32];
         {
             const f32x16 b0 = acc.block(2 * b, px), b1 = acc.block(2 * b + 1, px);      // out of the accumulator file HERE (see AccFile)
+            if constexpr (SC) {
+                const lds_f32x4 s4 = (lds_f32x4)(stepbuf + 32 * h);
 #pragma unroll
-            for (int q = 0; q < 16; ++q) { v[q] = b0[q] * MNET_SPLIT_WSCALE_INV; v[16 + q] = b1[q] * MNET_SPLIT_WSCALE_INV; }
-        }
-        // (two address spaces: an LDS-or-global pointer select would compile to flat loads, which wait on both counters)
-        auto scale32 = [&](const float* lds32, const float* glob32) __attribute__((always_inline)) {
-            if (rows_ok) {
-                typedef __attribute__((address_space(3))) const f32x4* lds_f32x4;     // (an explicit LDS pointer: the two arms cannot be merged into one load through a selected pointer)
-                const lds_f32x4 l4 = (lds_f32x4)lds32;
+                for (int q = 0; q < 16; ++q) { v[q] = b0[q] * s4[q >> 2][q & 3]; v[16 + q] = b1[q] * s4[4 + (q >> 2)][q & 3]; }
 #pragma unroll
-                for (int q = 0; q < 32; q += 4) { const f32x4 s4 = l4[q >> 2]; v[q] *= s4[0]; v[q + 1] *= s4[1]; v[q + 2] *= s4[2]; v[q + 3] *= s4[3]; }
+                for (int q = 0; q < 32; ++q) v[q] += bia[q >> 2][q & 3];
             } else {
+                // acc * 2^-8 + bias as ONE fma: the product is exact (a power of two), so the single rounding is the sum's — dma_epilogue_mx's value bit for bit
 #pragma unroll
-                for (int q = 0; q < 32; q += 4) { const f32x4 s4 = *reinterpret_cast<const f32x4*>(glob32 + q); v[q] *= s4[0]; v[q + 1] *= s4[1]; v[q + 2] *= s4[2]; v[q + 3] *= s4[3]; }
+                for (int q = 0; q < 16; ++q) { v[q] = __builtin_fmaf(b0[q], MNET_SPLIT_WSCALE_INV, bia[q >> 2][q & 3]); v[16 + q] = __builtin_fmaf(b1[q], MNET_SPLIT_WSCALE_INV, bia[4 + (q >> 2)][q & 3]); }
             }
-        };
-        if (p_out_scale) scale32(stepbuf + 32 * h, p_out_scale + (size_t)n_img * p.cout + co_l[b]);
-        if (p.bias) {
-            const float* bp = par_f + b * 64 + 32 * h;
-#pragma unroll
-            for (int q = 0; q < 32; q += 4) { const f32x4 b4 = *reinterpret_cast<const f32x4*>(bp + q); v[q] += b4[0]; v[q + 1] += b4[1]; v[q + 2] += b4[2]; v[q + 3] += b4[3]; }
         }
         if (p_res && pix < p.npix) {
             const float sl = hm_lo_scale((int)cur.re8);
@@ -198,14 +196,25 @@ __device__ __forceinline__ void w4_epilogue(const ConvArgs& p_, const ACC& acc, 
         }
         // (LeakyReLU as max(v, 0.2 v): one multiply + one max instead of compare / multiply / select — the same value for every input: 0.2 v > v exactly when v < 0,
         //  a NaN stays a NaN, -inf stays -inf; ReLU keeps act_apply_vec's form, whose relu(-inf) = NaN is wanted)
-        if (p.act == MNET_ACT_LRELU || p.act == MNET_ACT_LRELU_SQRT2) {
+        //  the launcher hands every other activation to the 8-wave tile: ONE in-place arm here, no second producer of v — hipcc copied all 32 values at the join of two.
+        //  v_max_f32 written out: fmaxf() adds a canonicalising v_max v, v, v per value)
+        if (p.act != MNET_ACT_NONE) {
             const float post = p.act == MNET_ACT_LRELU_SQRT2 ? 1.41421356237309515f : 1.f;
 #pragma unroll
-            for (int q = 0; q < 32; ++q) v[q] = fmaxf(v[q], v[q] * 0.2f) * post;
-        } else {
-            act_apply_vec<32, true>(v, p.act);
+            for (int q = 0; q < 32; q += 2) {
+                typedef float pk2 __attribute__((ext_vector_type(2)));
+                const pk2 t = pk2{v[q], v[q + 1]} * 0.2f;                  // (one v_pk_mul_f32 per pair)
+                float m0, m1;
+                asm("v_max_f32 %0, %1, %2" : "=v"(m0) : "v"(v[q]), "v"(t[0]));
+                asm("v_max_f32 %0, %1, %2" : "=v"(m1) : "v"(v[q + 1]), "v"(t[1]));
+                v[q] = m0 * post; v[q + 1] = m1 * post;
+            }
         }
-        if (p_post_scale) scale32(stepbuf + 64 + 32 * h, p_post_scale + (size_t)n_img * p.cout + co_l[b]);
+        if constexpr (SC) {
+            const lds_f32x4 s4 = (lds_f32x4)(stepbuf + 64 + 32 * h);
+#pragma unroll
+            for (int q = 0; q < 32; ++q) { v[q] *= s4[q >> 2][q & 3]; asm("" : "+v"(v[q])); }      // (opaque: hipcc would fold this product into the f16 conversion below — v_fma_mixlo_f16, ONE rounding: other bytes on ties)
+        }
         // GroupNorm statistics of this output, part 1 (see dma_epilogue_mx): two fp32 sums per lane over its 32 channels of ONE group
         float gs1 = 0.f, gs2 = 0.f;
         if (GN && gnp) {
@@ -706,6 +715,9 @@ int launch_conv_dma_w4(const ConvArgs& a, hipStream_t st) {
     const int lim = dma_grid_limit();
     static const bool env_one_tile = [] { const char* e = getenv("MNET_DMA_ONE_TILE"); return e && atoi(e) != 0; }();
     if (grid > lim && !a.one_tile_per_wg && !env_one_tile) grid = lim & ~7;
+    // the epilogue of this tile takes the per-image scale rows one float per lane (32-pixel fragments inside one image) and has the identity / LeakyReLU arms only:
+    // anything else runs on the 8-wave tile, same bytes
+    if ((a.howo & 31) != 0 || (a.act != MNET_ACT_NONE && a.act != MNET_ACT_LRELU && a.act != MNET_ACT_LRELU_SQRT2)) return launch_conv_dma(a, st, 15);
     const bool sc = a.out_scale || a.post_scale, rg = a.res || a.gn_partial;
     if (sc) return rg ? launch_w4<true, true>(b, grid, st) : launch_w4<true, false>(b, grid, st);
     return rg ? launch_w4<false, true>(b, grid, st) : launch_w4<false, false>(b, grid, st);

@@ -691,8 +691,9 @@ def test_one_wave_per_simd_tile_groupnorm_sums(case):
 
 
 def test_one_wave_per_simd_tile_scale_rows_of_maps_that_are_not_multiples_of_32_pixels():
-    """w4_epilogue stages out_scale / post_scale through the LDS one float per lane when a 32-pixel fragment lies in ONE image (ho * wo % 32 == 0); other maps take the
-    per-lane loads of dma_epilogue_mx — same bytes as the 8-wave tile either way (fragments straddling images, a pixel tail, ragged widths)"""
+    """w4_epilogue stages out_scale / post_scale through the LDS one float per lane, which needs a 32-pixel fragment inside ONE image (ho * wo % 32 == 0); a request for
+    id 16 on any other map is handed to the 8-wave tile by the launcher (as is an activation other than identity / LeakyReLU) — same bytes as the lock-step tile either
+    way (fragments straddling images, a pixel tail, ragged widths; the last shape runs on id 16 itself)"""
     ops = _ops()
     for (n, h, w) in ((20, 10, 10), (7, 12, 20), (9, 16, 16)):          # 100 / 240 / 256 pixels per image
         cin, cout = 64, 256

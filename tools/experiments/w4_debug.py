@@ -17,7 +17,17 @@ def run(n, h, w, cin, cout, k, detail=(), **kw):
         y = ops.conv2d(x, wp, cout, k, k, (1, 1), (k // 2, k // 2), algo=algo, **kw)
         torch.cuda.synchronize()
         outs.append(ops.convert(y, torch.float32).cpu())
+        raws = locals().setdefault("raws", [])
+        raws.append(packing.untag(y).view(torch.uint8).reshape(-1, 128).cpu())
     a, b = outs
+    db = (raws[0] != raws[1])
+    if db.any():
+        i = db.nonzero()
+        print("  RAW bytes differ: %d bytes in %d blocks; by byte offset in the block: %s; first: block %d byte %d ref 0x%02x got 0x%02x" % (
+            int(db.sum()), int(db.any(1).sum()), sorted(set(int(v) for v in i[:, 1]))[:16], int(i[0, 0]), int(i[0, 1]), int(raws[0][i[0, 0], i[0, 1]]), int(raws[1][i[0, 0], i[0, 1]])))
+        blk = int(i[0, 0])
+        print("   ref block:", " ".join("%02x" % int(v) for v in raws[0][blk][:100]))
+        print("   got block:", " ".join("%02x" % int(v) for v in raws[1][blk][:100]))
     npix = n * h * w
     a2, b2 = a.reshape(npix, cout), b.reshape(npix, cout)
     bad = ~((a2 == b2) | (torch.isnan(a2) & torch.isnan(b2)))
@@ -42,6 +52,23 @@ def run(n, h, w, cin, cout, k, detail=(), **kw):
         print("  first mismatch pixel %d channel %d: ref %r got %r" % (int(i[0]), int(i[1]), float(a2[i[0], i[1]]), float(b2[i[0], i[1]])))
 
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "scales":          # which epilogue term of the SC build differs?
+        n, cout = 2, 256
+        osc, psc, bias = (rnd((n, cout), 6).abs() + 0.5).cuda(), (rnd((n, cout), 7).abs() + 0.5).cuda(), rnd((cout,), 5).cuda()
+        run(n, 16, 32, 64, cout, 3)
+        run(n, 16, 32, 64, cout, 3, bias=bias)
+        run(n, 16, 32, 64, cout, 3, out_scale=osc)
+        run(n, 16, 32, 64, cout, 3, post_scale=psc)
+        run(n, 16, 32, 64, cout, 3, out_scale=osc, bias=bias)
+        run(n, 16, 32, 64, cout, 3, post_scale=psc, bias=bias)
+        run(n, 16, 32, 64, cout, 3, post_scale=psc, act=2)
+        run(n, 16, 32, 64, cout, 3, post_scale=psc, act=3)
+        run(n, 16, 32, 64, cout, 3, out_scale=osc, post_scale=psc, bias=bias, act=3)
+        n = 6
+        osc, psc = (rnd((n, cout), 173).abs() + 0.5).cuda(), (rnd((n, cout), 174).abs() + 0.5).cuda()
+        run(n, 64, 64, 64, cout, 3, out_scale=osc, post_scale=psc, bias=bias, act=3)
+        run(n, 64, 64, 64, cout, 3)
+        sys.exit(0)
     run(1, 16, 16, 32, 256, 1, detail=[(1, 3), (2, 0), (2, 1), (3, 0)])
     sys.exit(0)
     run(1, 16, 16, 64, 256, 1)
