@@ -156,7 +156,9 @@ enum { MNET_CONV_ALGO_AUTO = 0, MNET_CONV_ALGO_REG_STAGED = 1, MNET_CONV_ALGO_LD
                                        * same MFMA sequence as ids 0-6: identical bits.
                                        *   MNET_F16M launches, id 16 (round 6): the 256x256 tile with ONE wave per SIMD — 4 waves x 128x128 outputs, the accumulators
                                        *          in the accumulator register file (conv_dma_w4.hip) — AUTO's fp16+8 choice for cout >= 256, >= 65536 pixels; writes
-                                       *          mnet_conv_desc.gn_partial itself; same MFMA sequence per output as the fp16+8 ids 0-15: identical bytes */,
+                                       *          mnet_conv_desc.gn_partial itself; same MFMA sequence per output as the fp16+8 ids 0-15: identical bytes.  A launch
+                                       *          it is not built for — an activation other than NONE / LRELU / LRELU_SQRT2, ho * wo not a multiple of 32, more than
+                                       *          512 k-slabs — runs on id 15 (the 8-wave tile) under this id, same bytes */,
        MNET_CONV_ALGO_FLAG_ONE_TILE = 256 /* OR-ed in: LDS-DMA kernel launched with one workgroup per tile instead of its
                                             * persistent grid (A/B measurements only; same results) */,
        MNET_CONV_ALGO_FLAG_X1_CENTER = 512 /* OR-ed in (round 4): the SECOND source x1 contributes through the filter's CENTRE tap only —
