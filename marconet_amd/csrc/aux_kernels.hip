@@ -94,34 +94,39 @@ extern "C" int mnet_nhwc_to_nchw(const void* src, int32_t src_dtype, float* dst,
 // Per output the arithmetic is wy0*(wx0*a + wx1*b) + wy1*(wx0*c + wx1*d), horizontal first — ATen's order.
 // TD != T (round 5): the output in another storage type — the batched driver's image-only generator level reads the fp16+8 / split-half 64-px prior
 // and writes plain f16, which removes the separate mnet_convert pass over that map.  Both types carry 8 channels per chunk.
+// Round 6: a thread walks UPS_RUN consecutive input rows of its column and carries the horizontally interpolated rows y-1 and y in registers: 3 chunk loads (+ decodes)
+// per input pixel instead of 9 — the kernel was bound by its own instruction stream, not by the 4x write stream (4.0 TB/s where a one-trip copy of this storage's
+// access pattern does 5.97, tools/microbench/stream_variants.hip).  Same operands, same operation order per output: same bits.
+#ifndef MNET_UPS_RUN
+#define MNET_UPS_RUN 4
+#endif
 template <typename T, typename TD = T>
 __global__ void __launch_bounds__(256) upsample2x_kernel(const T* __restrict__ src, TD* __restrict__ dst,
                                                          int H, int W, int C, const float* __restrict__ scale,
-                                                         unsigned chunks_per_image) {
-    // grid: x strides over the 16-byte chunks of ONE input image (32-bit index math only), y = image
+                                                         unsigned items_per_image) {
+    // grid: x strides over the (chunk, column, row run) items of ONE input image (32-bit index math only), y = image
     constexpr int N = Vec<T>::N;
+    constexpr int R = MNET_UPS_RUN;
     static_assert(Vec<TD>::N == N, "source and destination chunks hold the same number of channels");
     const unsigned cpp = (unsigned)C / N;
     const int n = blockIdx.y;
     const T* sbase = src + (size_t)n * H * W * C;
     TD* dbase = dst + (size_t)n * 4 * H * W * C;
-    for (unsigned id = blockIdx.x * 256u + threadIdx.x; id < chunks_per_image; id += gridDim.x * 256u) {
-        const unsigned ch = id % cpp, pix = id / cpp;
-        const int x = (int)(pix % (unsigned)W), y = (int)(pix / (unsigned)W);
-        const int xm = max(x - 1, 0), xp = min(x + 1, W - 1), ym = max(y - 1, 0), yp = min(y + 1, H - 1);
+    for (unsigned id = blockIdx.x * 256u + threadIdx.x; id < items_per_image; id += gridDim.x * 256u) {
+        const unsigned ch = id % cpp, col = id / cpp;
+        const int x = (int)(col % (unsigned)W), y0 = (int)(col / (unsigned)W) * R, y1 = min(y0 + R, H);
+        const int xm = max(x - 1, 0), xp = min(x + 1, W - 1);
         const T* base = sbase + (size_t)ch * N;
-        float hl[3][N], hr[3][N];          // horizontally interpolated left / right output column for rows ym, y, yp
-        const int rows[3] = {ym, y, yp};
-#pragma unroll
-        for (int r = 0; r < 3; ++r) {
+        // horizontally interpolated left / right output column of one input row
+        auto hrow = [&](int r, float (&hl)[N], float (&hr)[N]) __attribute__((always_inline)) {
             float a[N], b[N], c[N];
-            const T* rp = base + (size_t)rows[r] * W * C;
+            const T* rp = base + (size_t)r * W * C;
             unpackr<T>(ldraw<T>(rp + (size_t)xm * C), a);
             unpackr<T>(ldraw<T>(rp + (size_t)x * C), b);
             unpackr<T>(ldraw<T>(rp + (size_t)xp * C), c);
 #pragma unroll
-            for (int j = 0; j < N; ++j) { hl[r][j] = 0.25f * a[j] + 0.75f * b[j]; hr[r][j] = 0.75f * b[j] + 0.25f * c[j]; }
-        }
+            for (int j = 0; j < N; ++j) { hl[j] = 0.25f * a[j] + 0.75f * b[j]; hr[j] = 0.75f * b[j] + 0.25f * c[j]; }
+        };
         float sc[N];
 #pragma unroll
         for (int j = 0; j < N; ++j) sc[j] = 1.f;
@@ -133,21 +138,33 @@ __global__ void __launch_bounds__(256) upsample2x_kernel(const T* __restrict__ s
                 sc[j] = s4[0]; sc[j + 1] = s4[1]; sc[j + 2] = s4[2]; sc[j + 3] = s4[3];
             }
         }
-        float o[N];
-        TD* q = dbase + ((size_t)(2 * y) * (2 * W) + 2 * x) * C + (size_t)ch * N;      // output pixel (2y, 2x)
+        float al[N], ar[N], bl[N], br[N], cl[N], cr[N];          // rows y-1 (clamped), y, y+1 (clamped)
+        hrow(max(y0 - 1, 0), al, ar);
+        hrow(y0, bl, br);
         const size_t orow = (size_t)2 * W * C;
+        for (int y = y0; y < y1; ++y) {
+            if (y + 1 < H) hrow(y + 1, cl, cr);
+            else {
 #pragma unroll
-        for (int j = 0; j < N; ++j) o[j] = (0.25f * hl[0][j] + 0.75f * hl[1][j]) * sc[j];
-        straw<TD>(q, packr<TD>(o));
+                for (int j = 0; j < N; ++j) { cl[j] = bl[j]; cr[j] = br[j]; }
+            }
+            float o[N];
+            TD* q = dbase + ((size_t)(2 * y) * (2 * W) + 2 * x) * C + (size_t)ch * N;      // output pixel (2y, 2x)
 #pragma unroll
-        for (int j = 0; j < N; ++j) o[j] = (0.25f * hr[0][j] + 0.75f * hr[1][j]) * sc[j];
-        straw<TD>(q + C, packr<TD>(o));
+            for (int j = 0; j < N; ++j) o[j] = (0.25f * al[j] + 0.75f * bl[j]) * sc[j];
+            straw<TD>(q, packr<TD>(o));
 #pragma unroll
-        for (int j = 0; j < N; ++j) o[j] = (0.75f * hl[1][j] + 0.25f * hl[2][j]) * sc[j];
-        straw<TD>(q + orow, packr<TD>(o));
+            for (int j = 0; j < N; ++j) o[j] = (0.25f * ar[j] + 0.75f * br[j]) * sc[j];
+            straw<TD>(q + C, packr<TD>(o));
 #pragma unroll
-        for (int j = 0; j < N; ++j) o[j] = (0.75f * hr[1][j] + 0.25f * hr[2][j]) * sc[j];
-        straw<TD>(q + orow + C, packr<TD>(o));
+            for (int j = 0; j < N; ++j) o[j] = (0.75f * bl[j] + 0.25f * cl[j]) * sc[j];
+            straw<TD>(q + orow, packr<TD>(o));
+#pragma unroll
+            for (int j = 0; j < N; ++j) o[j] = (0.75f * br[j] + 0.25f * cr[j]) * sc[j];
+            straw<TD>(q + orow + C, packr<TD>(o));
+#pragma unroll
+            for (int j = 0; j < N; ++j) { al[j] = bl[j]; ar[j] = br[j]; bl[j] = cl[j]; br[j] = cr[j]; }
+        }
     }
 }
 
@@ -160,8 +177,8 @@ extern "C" int mnet_upsample2x_convert_nhwc(const void* src, int32_t dtype, void
     MNET_CHECK_ALIGN(c % N == 0 && aligned16(src) && aligned16(dst) && aligned16(scale), "upsample2x: c %% %d != 0 or unaligned", N);
     MNET_CHECK_ALIGN(!is_split4(dtype) || (c % 32 == 0 && aligned128(src)), "upsample2x: split-half needs c %% 32 == 0, 128-byte aligned");
     MNET_CHECK_ALIGN(!is_split4(dst_dtype) || aligned128(dst), "upsample2x: split-half output must be 128-byte aligned");
-    const long long per = (long long)h * w * (c / N);             // one thread per input chunk
-    MNET_CHECK_ARG(per * 4 < (1ll << 31), "upsample2x: image too large");
+    MNET_CHECK_ARG((long long)h * w * (c / N) * 4 < (1ll << 31), "upsample2x: image too large");
+    const long long per = (long long)((h + MNET_UPS_RUN - 1) / MNET_UPS_RUN) * w * (c / N);      // one thread per (chunk, column, run of MNET_UPS_RUN input rows)
     const int gx = (int)((per + 255) / 256 < 2048 ? (per + 255) / 256 : 2048);
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     if (dst_dtype != dtype) {
@@ -950,7 +967,13 @@ extern "C" int mnet_affine_act_nhwc(const void* x, void* y, int32_t dtype, int32
                      "affine_act: c=%d unsupported or unaligned", c);
     const long long per = (long long)hw * (c / N);
     MNET_CHECK_ARG(per < (1ll << 31), "affine_act: image too large");
-    const int gx = (int)((per + 255) / 256 < 1024 ? (per + 255) / 256 : 1024);
+    // one trip per thread (round 6): with the grid capped at 1024 workgroups per image the SR-size maps made 8 trips per thread — 5.0-5.4 TB/s; uncapped 5.9 TB/s on the
+    // same box (profiles/r6af_*; the chip's plain copy: 6.3 with one 16-byte load per lane and one trip, 5.97 with this storage's half-line pattern).
+    // -DMNET_AFFINE_GX_CAP=1024 is the old form (A/B)
+#ifndef MNET_AFFINE_GX_CAP
+#define MNET_AFFINE_GX_CAP (1 << 20)
+#endif
+    const int gx = (int)((per + 255) / 256 < MNET_AFFINE_GX_CAP ? (per + 255) / 256 : MNET_AFFINE_GX_CAP);
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     if (dtype == MNET_F16) hipLaunchKernelGGL(affine_act_kernel<f16>, dim3(gx, n), dim3(256), 0, st, (const f16*)x, (f16*)y, c, scale, shift, swish, (unsigned)per);
     else if (dtype == MNET_F16X2) hipLaunchKernelGGL(affine_act_kernel<hs>, dim3(gx, n), dim3(256), 0, st, (const hs*)x, (hs*)y, c, scale, shift, swish, (unsigned)per);

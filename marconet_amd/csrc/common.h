@@ -46,6 +46,17 @@ __device__ __forceinline__ void stg16(void* p, u32x4 v) { *reinterpret_cast<u32x
 #ifndef MNET_NT_STRAW
 #define MNET_NT_STRAW 0
 #endif
+// the streaming kernels' 16-byte load (ldraw).  A/B build -DMNET_NT_LDRAW=1: non-temporal (read-once streams)
+#ifndef MNET_NT_LDRAW
+#define MNET_NT_LDRAW 0
+#endif
+__device__ __forceinline__ u32x4 ldg16s(const void* p) {
+#if MNET_NT_LDRAW
+    return __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(p));
+#else
+    return *reinterpret_cast<const u32x4*>(p);
+#endif
+}
 __device__ __forceinline__ void stg16s(void* p, u32x4 v) {
 #if MNET_NT_STRAW
     __builtin_nontemporal_store(v, reinterpret_cast<u32x4*>(p));
@@ -114,11 +125,11 @@ template <> struct Vec<hs> { static constexpr int N = 8; };
 template <typename T> struct Raw { u32x4 v; };
 template <> struct Raw<hs> { u32x4 hi, lo; };
 
-template <typename T> __device__ __forceinline__ Raw<T> ldraw(const T* p) { Raw<T> r; r.v = ldg16(p); return r; }
+template <typename T> __device__ __forceinline__ Raw<T> ldraw(const T* p) { Raw<T> r; r.v = ldg16s(p); return r; }
 template <> __device__ __forceinline__ Raw<hs> ldraw<hs>(const hs* p) {
     const uintptr_t a = reinterpret_cast<uintptr_t>(p);
     const unsigned char* q = reinterpret_cast<const unsigned char*>(a - ((a >> 5) & 3u) * 16u);
-    Raw<hs> r; r.hi = ldg16(q); r.lo = ldg16(q + 64); return r;
+    Raw<hs> r; r.hi = ldg16s(q); r.lo = ldg16s(q + 64); return r;
 }
 template <typename T> __device__ __forceinline__ void straw(T* p, const Raw<T>& r) { stg16s(p, r.v); }
 template <> __device__ __forceinline__ void straw<hs>(hs* p, const Raw<hs>& r) {
@@ -182,13 +193,13 @@ template <> __device__ __forceinline__ Raw<hm> ldraw<hm>(const hm* p) {
     const unsigned s = (unsigned)(a >> 5) & 3u;
     const unsigned char* blk = reinterpret_cast<const unsigned char*>(a - s * 32u);
     Raw<hm> r;
-    r.hi = ldg16(blk + s * 16u);
+    r.hi = ldg16s(blk + s * 16u);
 #if MNET_HM_SIMPLE_LOAD      // A/B build: three independent loads per lane (hi 16 B, lo 8 B, scale byte)
     r.lo8 = *reinterpret_cast<const u32x2*>(blk + 64 + hm_lo_slot((int)s) * 8);
     r.e8 = blk[96];
     return r;
 #endif
-    const u32x4 q = ldg16(blk + 64 + (s < 3u ? s : 2u) * 16u);           // (lane 3 re-reads lane 2's chunk: no divergence, same line)
+    const u32x4 q = ldg16s(blk + 64 + (s < 3u ? s : 2u) * 16u);           // (lane 3 re-reads lane 2's chunk: no divergence, same line)
     const unsigned a0 = (unsigned)__builtin_amdgcn_update_dpp(0, (int)q[0], 0x44, 0xf, 0xf, true);     // from lane (s & 1)
     const unsigned a1 = (unsigned)__builtin_amdgcn_update_dpp(0, (int)q[1], 0x44, 0xf, 0xf, true);
     const unsigned a2 = (unsigned)__builtin_amdgcn_update_dpp(0, (int)q[2], 0x44, 0xf, 0xf, true);
