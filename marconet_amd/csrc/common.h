@@ -127,14 +127,13 @@ template <> struct Raw<hs> { u32x4 hi, lo; };
 
 template <typename T> __device__ __forceinline__ Raw<T> ldraw(const T* p) { Raw<T> r; r.v = ldg16s(p); return r; }
 template <> __device__ __forceinline__ Raw<hs> ldraw<hs>(const hs* p) {
-    const uintptr_t a = reinterpret_cast<uintptr_t>(p);
-    const unsigned char* q = reinterpret_cast<const unsigned char*>(a - ((a >> 5) & 3u) * 16u);
+    // (the pointer itself is offset — through an integer round trip hipcc loses the address space and emits FLAT loads / stores, which wait on both counters)
+    const unsigned char* q = reinterpret_cast<const unsigned char*>(p) - (size_t)(((unsigned)reinterpret_cast<uintptr_t>(p) >> 5) & 3u) * 16u;
     Raw<hs> r; r.hi = ldg16s(q); r.lo = ldg16s(q + 64); return r;
 }
 template <typename T> __device__ __forceinline__ void straw(T* p, const Raw<T>& r) { stg16s(p, r.v); }
 template <> __device__ __forceinline__ void straw<hs>(hs* p, const Raw<hs>& r) {
-    const uintptr_t a = reinterpret_cast<uintptr_t>(p);
-    unsigned char* q = reinterpret_cast<unsigned char*>(a - ((a >> 5) & 3u) * 16u);
+    unsigned char* q = reinterpret_cast<unsigned char*>(p) - (size_t)(((unsigned)reinterpret_cast<uintptr_t>(p) >> 5) & 3u) * 16u;
     stg16s(q, r.hi); stg16s(q + 64, r.lo);
 }
 template <typename T> __device__ __forceinline__ Raw<T> zero_raw() { Raw<T> r; r.v = u32x4{0u, 0u, 0u, 0u}; return r; }
@@ -189,9 +188,8 @@ __device__ __forceinline__ int hm_lo_slot(int s) { return ((s & 1) << 1) | (s >>
 // halves and one quarter of the block's second half (lanes 0 / 1: the lo bytes of chunks (0, 2) / (1, 3), lane 2: the scale byte) —
 // then five DPP moves hand every lane its own 8 lo bytes and the block's exponent.
 template <> __device__ __forceinline__ Raw<hm> ldraw<hm>(const hm* p) {
-    const uintptr_t a = reinterpret_cast<uintptr_t>(p);
-    const unsigned s = (unsigned)(a >> 5) & 3u;
-    const unsigned char* blk = reinterpret_cast<const unsigned char*>(a - s * 32u);
+    const unsigned s = ((unsigned)reinterpret_cast<uintptr_t>(p) >> 5) & 3u;
+    const unsigned char* blk = reinterpret_cast<const unsigned char*>(p) - (size_t)(s * 32u);      // (pointer arithmetic, not integer: see ldraw<hs>)
     Raw<hm> r;
     r.hi = ldg16s(blk + s * 16u);
 #if MNET_HM_SIMPLE_LOAD      // A/B build: three independent loads per lane (hi 16 B, lo 8 B, scale byte)
@@ -214,9 +212,8 @@ template <> __device__ __forceinline__ Raw<hm> ldraw<hm>(const hm* p) {
 // 128-byte line is written (no partial-line write-back, deterministic padding).  (8-byte lo stores + predicated scale / padding
 // stores measured 24 % slower than the split-half kernels on the up-sample and GroupNorm-apply passes.)
 template <> __device__ __forceinline__ void straw<hm>(hm* p, const Raw<hm>& r) {
-    const uintptr_t a = reinterpret_cast<uintptr_t>(p);
-    const unsigned s = (unsigned)(a >> 5) & 3u;
-    unsigned char* blk = reinterpret_cast<unsigned char*>(a - s * 32u);
+    const unsigned s = ((unsigned)reinterpret_cast<uintptr_t>(p) >> 5) & 3u;
+    unsigned char* blk = reinterpret_cast<unsigned char*>(p) - (size_t)(s * 32u);
     stg16s(blk + s * 16u, r.hi);
     const unsigned p0 = (unsigned)__builtin_amdgcn_update_dpp(0, (int)r.lo8[0], 0x4E, 0xf, 0xf, true);     // partner (lane ^ 2) lo bytes
     const unsigned p1 = (unsigned)__builtin_amdgcn_update_dpp(0, (int)r.lo8[1], 0x4E, 0xf, 0xf, true);
