@@ -685,6 +685,9 @@ extern "C" int mnet_adain_crop_concat_split(const void* prior, const void* feat,
 // ============================================================================ ordered glyph scatter
 // grid (x-chunks of one feature row, image): a thread owns one 16-byte channel chunk of one COLUMN; the glyph that owns the
 // column (last glyph of the image whose window covers it) is looked up once and reused for all S rows
+#ifndef MNET_SCATTER_RUN
+#define MNET_SCATTER_RUN 8
+#endif
 template <typename T>
 __global__ void __launch_bounds__(256) glyph_scatter_kernel(const T* __restrict__ feat, const T* __restrict__ scale,
                                                             const T* __restrict__ shift, T* __restrict__ out,
@@ -704,24 +707,39 @@ __global__ void __launch_bounds__(256) glyph_scatter_kernel(const T* __restrict_
     const size_t row = (size_t)FW * C;
     const T* fp = feat + (size_t)b * S * row + (size_t)id * N;
     T* op = out + (size_t)b * S * row + (size_t)id * N;
+    // round 6: grid.z = runs of MNET_SCATTER_RUN rows — a thread walked all S rows of its column in a rolled loop (one row's loads in flight per thread, 5.1 TB/s where a
+    // one-trip stream of this storage does 5.9); now SCATTER_RUN rows per thread, unrolled, every row's loads requested before the first use
+    constexpr int R = MNET_SCATTER_RUN;
+    const int y0 = (int)blockIdx.z * R;
     if (owner < 0) {
-        for (int y = 0; y < S; ++y) straw<T>(op + (size_t)y * row, ldraw<T>(fp + (size_t)y * row));
+        Raw<T> raw[R];
+#pragma unroll
+        for (int k = 0; k < R; ++k) if (y0 + k < S) raw[k] = ldraw<T>(fp + (size_t)(y0 + k) * row);
+#pragma unroll
+        for (int k = 0; k < R; ++k) if (y0 + k < S) straw<T>(op + (size_t)(y0 + k) * row, raw[k]);
         return;
     }
     const size_t go = ((size_t)owner * S * S + ox) * C + (size_t)ch * N;     // + y*S*C per row
-    // (no unroll request: hipcc cannot honour one on this runtime-bounded loop behind the owner look-up — it warned and left the loop rolled; same code without it)
-    for (int y = 0; y < S; ++y) {
-        float f[N], sc[N], sh[N], o[N];
-        unpackr<T>(ldraw<T>(fp + (size_t)y * row), f);
-        unpackr<T>(ldraw<T>(scale + go + (size_t)y * S * C), sc);
-        unpackr<T>(ldraw<T>(shift + go + (size_t)y * S * C), sh);
+    Raw<T> rf[R], rs[R], rh[R];
 #pragma unroll
-        for (int j = 0; j < N; ++j) {
-            const float r = __fadd_rn(__fmul_rn(f[j], sc[j]), sh[j]);    // res = f*scale + shift  (:448)
-            o[j] = __fadd_rn(f[j], r);                                    // ori + res             (:449)
+    for (int k = 0; k < R; ++k)
+        if (y0 + k < S) {
+            rf[k] = ldraw<T>(fp + (size_t)(y0 + k) * row);
+            rs[k] = ldraw<T>(scale + go + (size_t)(y0 + k) * S * C);
+            rh[k] = ldraw<T>(shift + go + (size_t)(y0 + k) * S * C);
         }
-        straw<T>(op + (size_t)y * row, packr<T>(o));
-    }
+#pragma unroll
+    for (int k = 0; k < R; ++k)
+        if (y0 + k < S) {
+            float f[N], sc[N], sh[N], o[N];
+            unpackr<T>(rf[k], f); unpackr<T>(rs[k], sc); unpackr<T>(rh[k], sh);
+#pragma unroll
+            for (int j = 0; j < N; ++j) {
+                const float r = __fadd_rn(__fmul_rn(f[j], sc[j]), sh[j]);    // res = f*scale + shift  (:448)
+                o[j] = __fadd_rn(f[j], r);                                    // ori + res             (:449)
+            }
+            straw<T>(op + (size_t)(y0 + k) * row, packr<T>(o));
+        }
 }
 
 extern "C" int mnet_glyph_scatter_affine(const void* feat, const void* scale, const void* shift, void* out,
@@ -737,11 +755,13 @@ extern "C" int mnet_glyph_scatter_affine(const void* feat, const void* scale, co
                      "scatter: unaligned");
     MNET_CHECK_ARG(B <= 65535, "scatter: too many images");
     const int blocks = (int)(((long long)feat_w * (C / N) + 255) / 256);
+    const int runs = (S + MNET_SCATTER_RUN - 1) / MNET_SCATTER_RUN;
+    MNET_CHECK_ARG(runs <= 65535, "scatter: S too large");
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-    if (dtype == MNET_F16) hipLaunchKernelGGL(glyph_scatter_kernel<f16>, dim3(blocks, B), dim3(256), 0, st, (const f16*)feat, (const f16*)scale, (const f16*)shift, (f16*)out, S, C, feat_w, g_start, g_x1, g_w);
-    else if (dtype == MNET_F16X2) hipLaunchKernelGGL(glyph_scatter_kernel<hs>, dim3(blocks, B), dim3(256), 0, st, (const hs*)feat, (const hs*)scale, (const hs*)shift, (hs*)out, S, C, feat_w, g_start, g_x1, g_w);
-    else if (dtype == MNET_F16M) hipLaunchKernelGGL(glyph_scatter_kernel<hm>, dim3(blocks, B), dim3(256), 0, st, (const hm*)feat, (const hm*)scale, (const hm*)shift, (hm*)out, S, C, feat_w, g_start, g_x1, g_w);
-    else hipLaunchKernelGGL(glyph_scatter_kernel<float>, dim3(blocks, B), dim3(256), 0, st, (const float*)feat, (const float*)scale, (const float*)shift, (float*)out, S, C, feat_w, g_start, g_x1, g_w);
+    if (dtype == MNET_F16) hipLaunchKernelGGL(glyph_scatter_kernel<f16>, dim3(blocks, B, runs), dim3(256), 0, st, (const f16*)feat, (const f16*)scale, (const f16*)shift, (f16*)out, S, C, feat_w, g_start, g_x1, g_w);
+    else if (dtype == MNET_F16X2) hipLaunchKernelGGL(glyph_scatter_kernel<hs>, dim3(blocks, B, runs), dim3(256), 0, st, (const hs*)feat, (const hs*)scale, (const hs*)shift, (hs*)out, S, C, feat_w, g_start, g_x1, g_w);
+    else if (dtype == MNET_F16M) hipLaunchKernelGGL(glyph_scatter_kernel<hm>, dim3(blocks, B, runs), dim3(256), 0, st, (const hm*)feat, (const hm*)scale, (const hm*)shift, (hm*)out, S, C, feat_w, g_start, g_x1, g_w);
+    else hipLaunchKernelGGL(glyph_scatter_kernel<float>, dim3(blocks, B, runs), dim3(256), 0, st, (const float*)feat, (const float*)scale, (const float*)shift, (float*)out, S, C, feat_w, g_start, g_x1, g_w);
     MNET_LAUNCH_CHECK("glyph_scatter");
     return MNET_OK;
 }
