@@ -1092,6 +1092,9 @@ extern "C" int mnet_nonfinite_flag(const void* x, int32_t dtype, int64_t n, int3
 // them by the style and the three weight rows, the C/8 lanes of the pixel fold their partial sums by butterfly shuffles, lane 0
 // adds bias and the up-sampled skip (4 taps of the fp32 [N,H/2,W/2,4] image below, horizontal first like ATen) and writes fp32 RGB0.
 //   out[n,y,x,o] = tanh( sb[n] * sum_c W[o,c] * (x[n,y,x,c] * s[n,c]) + bias[o] + up2(skip)[n,y,x,o] )
+#ifndef MNET_TORGB_DPP
+#define MNET_TORGB_DPP 1
+#endif
 template <typename T>
 __global__ void __launch_bounds__(256) torgb_kernel(const T* __restrict__ x, const float* __restrict__ wgt, const float* __restrict__ style,
                                                     const float* __restrict__ sb, const float* __restrict__ bias,
@@ -1127,8 +1130,28 @@ __global__ void __launch_bounds__(256) torgb_kernel(const T* __restrict__ x, con
         float p0 = 0.f, p1 = 0.f, p2 = 0.f;
 #pragma unroll
         for (int j = 0; j < 8; ++j) { const float m = v[j] * s8[j]; p0 = fmaf(m, w0[j], p0); p1 = fmaf(m, w1[j], p1); p2 = fmaf(m, w2[j], p2); }
+#if MNET_TORGB_DPP
+        // fold over the pixel's C/8 lanes on the VALU (round 6): the butterfly of __shfl_xor is ds_bpermute — 12-18 LDS instructions per pixel, and the ONE LDS pipe of the
+        // CU was what bounded this read-only stream (3.1 TB/s).  DPP: quad, half-row and row mirrors leave the sum of each 16-lane row in all its lanes; row_bcast15 / 31 add
+        // the rows below into the last row of a 32- / 64-lane pixel — whose last lane writes
+        auto fold = [&](float v) __attribute__((always_inline)) -> float {
+            auto dpp = [](float q, auto ctrl, auto rmask) __attribute__((always_inline)) {
+                return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, q), decltype(ctrl)::value, decltype(rmask)::value, 0xf, false));
+            };
+            v += dpp(v, std::integral_constant<int, 0xB1>{}, std::integral_constant<int, 0xf>{});       // quad_perm [1,0,3,2]
+            v += dpp(v, std::integral_constant<int, 0x4E>{}, std::integral_constant<int, 0xf>{});       // quad_perm [2,3,0,1]
+            v += dpp(v, std::integral_constant<int, 0x141>{}, std::integral_constant<int, 0xf>{});      // row_half_mirror
+            v += dpp(v, std::integral_constant<int, 0x140>{}, std::integral_constant<int, 0xf>{});      // row_mirror
+            if (cpp > 16) v += dpp(v, std::integral_constant<int, 0x142>{}, std::integral_constant<int, 0xa>{});      // row_bcast15 into rows 1, 3
+            if (cpp > 32) v += dpp(v, std::integral_constant<int, 0x143>{}, std::integral_constant<int, 0xc>{});      // row_bcast31 into rows 2, 3
+            return v;
+        };
+        p0 = fold(p0); p1 = fold(p1); p2 = fold(p2);
+        if (ch != cpp - 1) continue;
+#else
         for (int o = 1; o < cpp; o <<= 1) { p0 += __shfl_xor(p0, o, 64); p1 += __shfl_xor(p1, o, 64); p2 += __shfl_xor(p2, o, 64); }
         if (ch != 0) continue;
+#endif
         float r0 = p0 * osc + bias[0], r1 = p1 * osc + bias[1], r2 = p2 * osc + bias[2];
         if (kb) {
             const int y = pix / W, xx = pix - y * W;
