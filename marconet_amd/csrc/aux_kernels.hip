@@ -952,16 +952,20 @@ extern "C" int mnet_fused_bias_act(const float* x, const float* bias, float* y, 
 }
 
 // ============================================================================ per-(n,c) affine (+ swish), elementwise
-// grid: x strides over the chunks of ONE image with a stride that is a multiple of chunks-per-pixel, so a thread
-// always lands on the same channel chunk: its 2x8 scale/shift values are loaded once, outside the loop.
-template <typename T>
+// grid: x covers the chunks of ONE image, PPT chunks per thread 256 apart (256 % chunks-per-pixel == 0: a thread always lands on the same channel chunk, its 2x8
+// scale / shift values are loaded once); y = image.
+// Round 6: ONE trip per thread (the grid was capped at 1024 workgroups per image: 8 trips on the SR-size maps, 5.0-5.4 TB/s; uncapped 5.9 on the same box — the rate of a
+// one-trip copy with this storage's half-line pattern, tools/microbench/stream_variants.hip), and PPT = 2 chunks per thread — both loads requested before the first
+// use — where a pixel has >= 128 chunks (C = 1024, the fuse blocks' concatenated map): there the 64 bytes of scale / shift per thread are as many bytes again as the chunk
+// itself: 4.7 -> 5.3 TB/s; on every smaller C one chunk per thread measured the same or better, 4 per thread worse everywhere (tools/experiments/gn_apply_shapes.py).
+template <typename T, int PPT>
 __global__ void __launch_bounds__(256) affine_act_kernel(const T* __restrict__ x, T* __restrict__ y, int C,
                                                          const float* __restrict__ scale, const float* __restrict__ shift,
                                                          int swish, unsigned chunks_per_image) {
     constexpr int N = Vec<T>::N;
     const unsigned cpp = (unsigned)C / N;
     const int n = blockIdx.y;
-    const unsigned first = blockIdx.x * 256u + threadIdx.x;
+    const unsigned first = blockIdx.x * (256u * PPT) + threadIdx.x;
     const unsigned ch = first % cpp;
     float sc[N], sh[N];
     const size_t so = (size_t)n * C + (size_t)ch * N;
@@ -975,17 +979,37 @@ __global__ void __launch_bounds__(256) affine_act_kernel(const T* __restrict__ x
     }
     const T* xb = x + (size_t)n * chunks_per_image * N;
     T* yb = y + (size_t)n * chunks_per_image * N;
-    for (unsigned id = first; id < chunks_per_image; id += gridDim.x * 256u) {      // stride % cpp == 0 (host)
+    Raw<T> r[PPT];
+#pragma unroll
+    for (int k = 0; k < PPT; ++k) {
+        const unsigned id = first + 256u * k;
+        r[k] = id < chunks_per_image ? ldraw<T>(xb + (size_t)id * N) : zero_raw<T>();      // (a quad of lanes shares a block: all four in range or none — per % 4 == 0)
+    }
+#pragma unroll
+    for (int k = 0; k < PPT; ++k) {
+        const unsigned id = first + 256u * k;
         float v[N];
-        unpackr<T>(ldraw<T>(xb + (size_t)id * N), v);
+        unpackr<T>(r[k], v);
 #pragma unroll
         for (int j = 0; j < N; ++j) {
             float t = v[j] * sc[j] + sh[j];
             if (swish) t = t * __builtin_amdgcn_rcpf(1.f + __expf(-t));       // v_exp_f32 / v_rcp_f32: ~1 ulp each
             v[j] = t;
         }
-        straw<T>(yb + (size_t)id * N, packr<T>(v));
+        const Raw<T> o = packr<T>(v);
+        if (id < chunks_per_image) straw<T>(yb + (size_t)id * N, o);
     }
+}
+
+template <typename T>
+static void affine_act_launch(const void* x, void* y, int n, int c, long long per, const float* scale, const float* shift, int swish, hipStream_t st) {
+    constexpr int N = Vec<T>::N;
+    static const int env_ppt = [] { const char* e = getenv("MNET_AFFINE_PPT"); return e ? atoi(e) : 0; }();      // A/B: 1, 2 or 4 for every launch
+    const int ppt = env_ppt == 1 || env_ppt == 2 || env_ppt == 4 ? env_ppt : (c / N >= 128 ? 2 : 1);
+    const int gx = (int)((per + 256 * ppt - 1) / (256 * ppt));
+    if (ppt == 4) hipLaunchKernelGGL((affine_act_kernel<T, 4>), dim3(gx, n), dim3(256), 0, st, (const T*)x, (T*)y, c, scale, shift, swish, (unsigned)per);
+    else if (ppt == 2) hipLaunchKernelGGL((affine_act_kernel<T, 2>), dim3(gx, n), dim3(256), 0, st, (const T*)x, (T*)y, c, scale, shift, swish, (unsigned)per);
+    else hipLaunchKernelGGL((affine_act_kernel<T, 1>), dim3(gx, n), dim3(256), 0, st, (const T*)x, (T*)y, c, scale, shift, swish, (unsigned)per);
 }
 
 extern "C" int mnet_affine_act_nhwc(const void* x, void* y, int32_t dtype, int32_t n, int32_t hw, int32_t c,
@@ -998,18 +1022,11 @@ extern "C" int mnet_affine_act_nhwc(const void* x, void* y, int32_t dtype, int32
                      "affine_act: c=%d unsupported or unaligned", c);
     const long long per = (long long)hw * (c / N);
     MNET_CHECK_ARG(per < (1ll << 31), "affine_act: image too large");
-    // one trip per thread (round 6): with the grid capped at 1024 workgroups per image the SR-size maps made 8 trips per thread — 5.0-5.4 TB/s; uncapped 5.9 TB/s on the
-    // same box (profiles/r6af_*; the chip's plain copy: 6.3 with one 16-byte load per lane and one trip, 5.97 with this storage's half-line pattern).
-    // -DMNET_AFFINE_GX_CAP=1024 is the old form (A/B)
-#ifndef MNET_AFFINE_GX_CAP
-#define MNET_AFFINE_GX_CAP (1 << 20)
-#endif
-    const int gx = (int)((per + 255) / 256 < MNET_AFFINE_GX_CAP ? (per + 255) / 256 : MNET_AFFINE_GX_CAP);
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-    if (dtype == MNET_F16) hipLaunchKernelGGL(affine_act_kernel<f16>, dim3(gx, n), dim3(256), 0, st, (const f16*)x, (f16*)y, c, scale, shift, swish, (unsigned)per);
-    else if (dtype == MNET_F16X2) hipLaunchKernelGGL(affine_act_kernel<hs>, dim3(gx, n), dim3(256), 0, st, (const hs*)x, (hs*)y, c, scale, shift, swish, (unsigned)per);
-    else if (dtype == MNET_F16M) hipLaunchKernelGGL(affine_act_kernel<hm>, dim3(gx, n), dim3(256), 0, st, (const hm*)x, (hm*)y, c, scale, shift, swish, (unsigned)per);
-    else hipLaunchKernelGGL(affine_act_kernel<float>, dim3(gx, n), dim3(256), 0, st, (const float*)x, (float*)y, c, scale, shift, swish, (unsigned)per);
+    if (dtype == MNET_F16) affine_act_launch<f16>(x, y, n, c, per, scale, shift, swish, st);
+    else if (dtype == MNET_F16X2) affine_act_launch<hs>(x, y, n, c, per, scale, shift, swish, st);
+    else if (dtype == MNET_F16M) affine_act_launch<hm>(x, y, n, c, per, scale, shift, swish, st);
+    else affine_act_launch<float>(x, y, n, c, per, scale, shift, swish, st);
     MNET_LAUNCH_CHECK("affine_act");
     return MNET_OK;
 }
