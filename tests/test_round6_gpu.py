@@ -96,3 +96,67 @@ def test_lo_byte_encoders_agree_on_subnormal_blocks():
     assert torch.equal(yb, host), "conv epilogue encoder differs from the host packer on subnormal blocks"
     dec = ops.convert(y, torch.float32).cpu()
     assert torch.isfinite(dec).all() and torch.equal(dec, mxfmt.unpack_act(host, cout))
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# round 6, last pass: the streaming kernels' new launch shapes against plain torch on the values the storage holds
+def _mx_roundtrip(x_nchw):
+    """NCHW fp32 -> (fp16+8 NHWC tensor on the device, the values it holds as NCHW fp32 on the host)"""
+    from marconet_amd import ops, packing
+    xs = ops.convert(x_nchw.permute(0, 2, 3, 1).contiguous().to(DEV), packing.MX_DTYPE)
+    return xs, ops.convert(xs, torch.float32).cpu().permute(0, 3, 1, 2).contiguous()
+
+
+@pytest.mark.parametrize("shape", [(8, 64, 9, 12), (16, 32, 4, 4), (3, 64, 13, 5), (8, 512, 6, 6)])
+def test_upsample_row_runs_in_xcd_aware_order(shape):
+    """up-sample: runs of 4 input rows per thread (a last, shorter run when H % 4 != 0) and the XCD-aware workgroup order, taken when the (image, workgroup) count is a
+    multiple of 8 (first, second and last case) and not (third) — bilinear x2 of the stored values, within the storage's rounding"""
+    from marconet_amd import ops
+    xs, xv = _mx_roundtrip(_rnd(shape, 301, 1.5))
+    ref = F.interpolate(xv, scale_factor=2, mode="bilinear", align_corners=False)
+    y = ops.convert(ops.upsample2x(xs), torch.float32).cpu().permute(0, 3, 1, 2)
+    assert y.shape == ref.shape and (y - ref).abs().max().item() <= 3e-5 * max(1.0, ref.abs().max().item())
+    sc = (_rnd((shape[0], shape[1]), 302).abs() + 0.5)
+    y16 = ops.upsample2x(xs, scale=sc.to(DEV), out_dtype=torch.float16).float().cpu().permute(0, 3, 1, 2)
+    ref16 = ref * sc[:, :, None, None]
+    assert (y16 - ref16).abs().max().item() <= 1e-3 * max(1.0, ref16.abs().max().item())
+
+
+@pytest.mark.parametrize("shape", [(3, 1024, 5, 9), (2, 1024, 32, 32), (5, 512, 7, 9), (2, 64, 33, 17)])
+def test_groupnorm_apply_one_trip_and_two_chunks_per_thread(shape):
+    """GroupNorm apply + swish: one trip per thread on every map; two chunks per thread where a pixel has >= 128 chunks (C = 1024), with a tail workgroup whose second
+    chunk lies beyond the image (first case: 5 760 chunks = 11 workgroups of 512 + a quarter)"""
+    from marconet_amd import ops
+    n, c, h, w = shape
+    xs, xv = _mx_roundtrip(_rnd(shape, 311, 2.0) + 0.3)
+    sc, sh = _rnd((n, c), 312).abs() + 0.5, _rnd((n, c), 313)
+    for swish in (True, False):
+        t = xv * sc[:, :, None, None] + sh[:, :, None, None]
+        ref = t * torch.sigmoid(t) if swish else t
+        y = ops.convert(ops.affine_act(xs, sc.to(DEV), sh.to(DEV), swish=swish), torch.float32).cpu().permute(0, 3, 1, 2)
+        assert (y - ref).abs().max().item() <= 4e-5 * max(1.0, ref.abs().max().item())
+    y_in_place = ops.affine_act(xs, sc.to(DEV), sh.to(DEV), swish=True, out=xs)
+    assert y_in_place is xs
+    t = xv * sc[:, :, None, None] + sh[:, :, None, None]
+    assert (ops.convert(xs, torch.float32).cpu().permute(0, 3, 1, 2) - t * torch.sigmoid(t)).abs().max().item() <= 4e-5 * max(1.0, t.abs().max().item())
+
+
+def test_glyph_scatter_row_runs_with_a_short_last_run():
+    """scatter: runs of 8 rows per thread; S = 12 leaves a run of 4 (the model's maps are 32 / 64 rows); columns no glyph owns are copied"""
+    from marconet_amd import ops
+    B, C, S, FW = 2, 64, 12, 40
+    feat_s, feat = _mx_roundtrip(_rnd((B, C, S, FW), 321))
+    windows = [(0, 3, 9), (0, 8, 12), (1, 25, 12)]                      # (image, x1, width): the second glyph overwrites columns 8..11 of the first
+    G = len(windows)
+    sc_s, sc = _mx_roundtrip(_rnd((G, C, S, S), 322) * 0.5)
+    sh_s, sh = _mx_roundtrip(_rnd((G, C, S, S), 323) * 0.5)
+    g_start = torch.tensor([0, 2, 3], dtype=torch.int32)
+    g_x1 = torch.tensor([wd[1] for wd in windows], dtype=torch.int32)
+    g_w = torch.tensor([wd[2] for wd in windows], dtype=torch.int32)
+    out = ops.convert(ops.glyph_scatter_affine(feat_s, sc_s, sh_s, g_start.to(DEV), g_x1.to(DEV), g_w.to(DEV)), torch.float32).cpu().permute(0, 3, 1, 2)
+    ref = feat.clone()
+    for g, (b, x1, gw) in enumerate(windows):                            # models/networks.py:446-449 — res = f * scale + shift on the window, last writer wins; out = ori + res
+        f = feat[b, :, :, x1:x1 + gw]
+        ref[b, :, :, x1:x1 + gw] = f + (f * sc[g, :, :, :gw] + sh[g, :, :, :gw])
+    assert (out - ref).abs().max().item() <= 4e-5 * max(1.0, ref.abs().max().item())
+    assert torch.equal(out[0, :, :, 20:], feat[0, :, :, 20:]) and torch.equal(out[1, :, :, :25], feat[1, :, :, :25])
