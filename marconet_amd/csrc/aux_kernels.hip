@@ -1139,6 +1139,42 @@ __global__ void __launch_bounds__(256) torgb_kernel(const T* __restrict__ x, con
             const int pq = pix0 + u * step;
             ld8<T>(xb + (size_t)(pq < HW ? pq : pix0) * C, vv[u]);
         }
+#if MNET_TORGB_DPP
+        // the fold over a pixel's C/8 lanes on the VALU (round 6): the butterfly of __shfl_xor is ds_bpermute — 12-18 LDS instructions per pixel, and the ONE LDS pipe of the
+        // CU was what bounded this read-only stream (3.1 TB/s).  DPP: quad, half-row and row mirrors leave the sum of each 16-lane row in all its lanes; row_bcast15 / 31 add
+        // the rows below into the LAST row of a 32- / 64-lane pixel, whose 16 lanes (8 when C = 64) then all hold the pixel's sums.
+        auto fold = [&](float v) __attribute__((always_inline)) -> float {
+            auto dpp = [](float q, auto ctrl, auto rmask) __attribute__((always_inline)) {
+                return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, q), decltype(ctrl)::value, decltype(rmask)::value, 0xf, false));
+            };
+            v += dpp(v, std::integral_constant<int, 0xB1>{}, std::integral_constant<int, 0xf>{});       // quad_perm [1,0,3,2]
+            v += dpp(v, std::integral_constant<int, 0x4E>{}, std::integral_constant<int, 0xf>{});       // quad_perm [2,3,0,1]
+            v += dpp(v, std::integral_constant<int, 0x141>{}, std::integral_constant<int, 0xf>{});      // row_half_mirror
+            if (cpp > 8) v += dpp(v, std::integral_constant<int, 0x140>{}, std::integral_constant<int, 0xf>{});      // row_mirror (C = 64: a pixel is 8 lanes, half a row)
+            if (cpp > 16) v += dpp(v, std::integral_constant<int, 0x142>{}, std::integral_constant<int, 0xa>{});      // row_bcast15 into rows 1, 3
+            if (cpp > 32) v += dpp(v, std::integral_constant<int, 0x143>{}, std::integral_constant<int, 0xc>{});      // row_bcast31 into rows 2, 3
+            return v;
+        };
+        // the U pixels' tails (bias, the four skip taps, three tanh, the store: ~150 instructions) run ONCE, in U lanes of the pixel's last row — lane u of that row takes
+        // pixel u — instead of U times with one lane active each: the tails were most of this kernel's instruction stream
+        float q0[U], q1[U], q2[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const float* v = vv[u];
+            float p0 = 0.f, p1 = 0.f, p2 = 0.f;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { const float m = v[j] * s8[j]; p0 = fmaf(m, w0[j], p0); p1 = fmaf(m, w1[j], p1); p2 = fmaf(m, w2[j], p2); }
+            q0[u] = fold(p0); q1[u] = fold(p1); q2[u] = fold(p2);
+        }
+        const int mu = ch - (cpp > 16 ? cpp - 16 : 0);               // lane of the pixel's last row (< 0: an earlier row)
+        if (mu < 0 || mu >= U) continue;
+        float p0 = q0[0], p1 = q1[0], p2 = q2[0];
+#pragma unroll
+        for (int u = 1; u < U; ++u) { p0 = mu == u ? q0[u] : p0; p1 = mu == u ? q1[u] : p1; p2 = mu == u ? q2[u] : p2; }
+        const int pix = pix0 + mu * step;
+        if (pix >= HW) continue;
+        {
+#else
 #pragma unroll
         for (int u = 0; u < U; ++u) {
         const int pix = pix0 + u * step;
@@ -1147,25 +1183,6 @@ __global__ void __launch_bounds__(256) torgb_kernel(const T* __restrict__ x, con
         float p0 = 0.f, p1 = 0.f, p2 = 0.f;
 #pragma unroll
         for (int j = 0; j < 8; ++j) { const float m = v[j] * s8[j]; p0 = fmaf(m, w0[j], p0); p1 = fmaf(m, w1[j], p1); p2 = fmaf(m, w2[j], p2); }
-#if MNET_TORGB_DPP
-        // fold over the pixel's C/8 lanes on the VALU (round 6): the butterfly of __shfl_xor is ds_bpermute — 12-18 LDS instructions per pixel, and the ONE LDS pipe of the
-        // CU was what bounded this read-only stream (3.1 TB/s).  DPP: quad, half-row and row mirrors leave the sum of each 16-lane row in all its lanes; row_bcast15 / 31 add
-        // the rows below into the last row of a 32- / 64-lane pixel — whose last lane writes
-        auto fold = [&](float v) __attribute__((always_inline)) -> float {
-            auto dpp = [](float q, auto ctrl, auto rmask) __attribute__((always_inline)) {
-                return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, q), decltype(ctrl)::value, decltype(rmask)::value, 0xf, false));
-            };
-            v += dpp(v, std::integral_constant<int, 0xB1>{}, std::integral_constant<int, 0xf>{});       // quad_perm [1,0,3,2]
-            v += dpp(v, std::integral_constant<int, 0x4E>{}, std::integral_constant<int, 0xf>{});       // quad_perm [2,3,0,1]
-            v += dpp(v, std::integral_constant<int, 0x141>{}, std::integral_constant<int, 0xf>{});      // row_half_mirror
-            v += dpp(v, std::integral_constant<int, 0x140>{}, std::integral_constant<int, 0xf>{});      // row_mirror
-            if (cpp > 16) v += dpp(v, std::integral_constant<int, 0x142>{}, std::integral_constant<int, 0xa>{});      // row_bcast15 into rows 1, 3
-            if (cpp > 32) v += dpp(v, std::integral_constant<int, 0x143>{}, std::integral_constant<int, 0xc>{});      // row_bcast31 into rows 2, 3
-            return v;
-        };
-        p0 = fold(p0); p1 = fold(p1); p2 = fold(p2);
-        if (ch != cpp - 1) continue;
-#else
         for (int o = 1; o < cpp; o <<= 1) { p0 += __shfl_xor(p0, o, 64); p1 += __shfl_xor(p1, o, 64); p2 += __shfl_xor(p2, o, 64); }
         if (ch != 0) continue;
 #endif

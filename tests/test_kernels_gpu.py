@@ -757,7 +757,7 @@ def test_style_rows_and_scaled_demod():
 
 
 @pytest.mark.parametrize("dtype", ALL_DTYPES)
-@pytest.mark.parametrize("c,hw", [(128, (6, 10)), (512, (6, 10)), (256, (64, 64)), (128, (36, 50))])
+@pytest.mark.parametrize("c,hw", [(128, (6, 10)), (512, (6, 10)), (256, (64, 64)), (128, (36, 50)), (64, (10, 6)), (512, (2, 2))])
 def test_torgb_kernel(c, hw, dtype):
     """ToRGB.forward (models/networks.py:313-321): modulated 1x1 conv (no demodulation) + bias + bilinear x2 of the skip + tanh
     (the larger maps: several trips per workgroup, a ragged last trip)"""
