@@ -1112,6 +1112,9 @@ extern "C" int mnet_nonfinite_flag(const void* x, int32_t dtype, int64_t n, int3
 #ifndef MNET_TORGB_DPP
 #define MNET_TORGB_DPP 1
 #endif
+#ifndef MNET_TORGB_U
+#define MNET_TORGB_U 4      // pixels per thread and trip (their loads are issued together; their tails run in U lanes at once)
+#endif
 template <typename T>
 __global__ void __launch_bounds__(256) torgb_kernel(const T* __restrict__ x, const float* __restrict__ wgt, const float* __restrict__ style,
                                                     const float* __restrict__ sb, const float* __restrict__ bias,
@@ -1130,7 +1133,7 @@ __global__ void __launch_bounds__(256) torgb_kernel(const T* __restrict__ x, con
     const int h2 = H >> 1, w2_ = W >> 1;
     const float* kb = skip ? skip + (size_t)n * h2 * w2_ * 4 : nullptr;
     // four pixels per trip: their loads are issued together (one load in flight per lane measured 2.7 TB/s on the 128-px level)
-    constexpr int U = 4;
+    constexpr int U = MNET_TORGB_U;
     const int step = gridDim.x * ppb;
     for (int pix0 = blockIdx.x * ppb + pl; pix0 < HW; pix0 += U * step) {
         float vv[U][8];
@@ -1211,7 +1214,7 @@ extern "C" int mnet_torgb(const void* x, int32_t dtype, int32_t n, int32_t h, in
     MNET_CHECK_ARG(c >= 64 && c <= 512 && (c & (c - 1)) == 0, "torgb: c=%d (supported: 64, 128, 256, 512)", c);
     MNET_CHECK_ARG(!skip || (h % 2 == 0 && w % 2 == 0), "torgb: a skip image needs even h, w");
     MNET_CHECK_ALIGN(aligned16(x) && aligned16(skip) && aligned16(out) && (!is_split4(dtype) || aligned128(x)), "torgb: unaligned pointer");
-    const long long groups = (((long long)h * w + (256 / (c / 8)) - 1) / (256 / (c / 8)) + 3) / 4;      // four pixels per thread and trip
+    const long long groups = (((long long)h * w + (256 / (c / 8)) - 1) / (256 / (c / 8)) + MNET_TORGB_U - 1) / MNET_TORGB_U;      // MNET_TORGB_U pixels per thread and trip
     // round 5: a workgroup makes (up to) four trips — its prologue (this thread's 8 style values and 3 x 8 weights: 32 loads) was paid once
     // per trip on the 64- and 128-px levels, whose 128 / 256 trips per image had one workgroup each; MNET_TORGB_TRIPS=1 is that form (A/B knob)
     static const int trips = [] { const char* e = getenv("MNET_TORGB_TRIPS"); return e && atoi(e) > 0 ? atoi(e) : 4; }();
