@@ -103,6 +103,9 @@ extern "C" int mnet_nhwc_to_nchw(const void* src, int32_t src_dtype, float* dst,
 #ifndef MNET_UPS_XCD
 #define MNET_UPS_XCD 1
 #endif
+#ifndef MNET_UPS_ZIGZAG
+#define MNET_UPS_ZIGZAG 1
+#endif
 template <typename T, typename TD = T>
 __global__ void __launch_bounds__(256) upsample2x_kernel(const T* __restrict__ src, TD* __restrict__ dst,
                                                          int H, int W, int C, const float* __restrict__ scale,
@@ -150,15 +153,8 @@ __global__ void __launch_bounds__(256) upsample2x_kernel(const T* __restrict__ s
             }
         }
         float al[N], ar[N], bl[N], br[N], cl[N], cr[N];          // rows y-1 (clamped), y, y+1 (clamped)
-        hrow(max(y0 - 1, 0), al, ar);
-        hrow(y0, bl, br);
         const size_t orow = (size_t)2 * W * C;
-        for (int y = y0; y < y1; ++y) {
-            if (y + 1 < H) hrow(y + 1, cl, cr);
-            else {
-#pragma unroll
-                for (int j = 0; j < N; ++j) { cl[j] = bl[j]; cr[j] = br[j]; }
-            }
+        auto emit = [&](int y) __attribute__((always_inline)) {
             float o[N];
             TD* q = dbase + ((size_t)(2 * y) * (2 * W) + 2 * x) * C + (size_t)ch * N;      // output pixel (2y, 2x)
 #pragma unroll
@@ -173,8 +169,35 @@ __global__ void __launch_bounds__(256) upsample2x_kernel(const T* __restrict__ s
 #pragma unroll
             for (int j = 0; j < N; ++j) o[j] = (0.75f * br[j] + 0.25f * cr[j]) * sc[j];
             straw<TD>(q + orow + C, packr<TD>(o));
+        };
+        // Odd runs walk UP: a run and its lower neighbour then meet at their common border at the same time (both at the end, or both at the start, of their walks) — the
+        // two border rows each of them reads were fetched from HBM twice, the second reader finding them flushed from the L2 by the 4x write stream (FETCH_SIZE: 1.5x the input)
+        if (!MNET_UPS_ZIGZAG || ((y0 / R) & 1) == 0) {
+            hrow(max(y0 - 1, 0), al, ar);
+            hrow(y0, bl, br);
+            for (int y = y0; y < y1; ++y) {
+                if (y + 1 < H) hrow(y + 1, cl, cr);
+                else {
 #pragma unroll
-            for (int j = 0; j < N; ++j) { al[j] = bl[j]; ar[j] = br[j]; bl[j] = cl[j]; br[j] = cr[j]; }
+                    for (int j = 0; j < N; ++j) { cl[j] = bl[j]; cr[j] = br[j]; }
+                }
+                emit(y);
+#pragma unroll
+                for (int j = 0; j < N; ++j) { al[j] = bl[j]; ar[j] = br[j]; bl[j] = cl[j]; br[j] = cr[j]; }
+            }
+        } else {
+            hrow(min(y1, H - 1), cl, cr);
+            hrow(y1 - 1, bl, br);
+            for (int y = y1 - 1; y >= y0; --y) {
+                if (y > 0) hrow(y - 1, al, ar);
+                else {
+#pragma unroll
+                    for (int j = 0; j < N; ++j) { al[j] = bl[j]; ar[j] = br[j]; }
+                }
+                emit(y);
+#pragma unroll
+                for (int j = 0; j < N; ++j) { cl[j] = bl[j]; cr[j] = br[j]; bl[j] = al[j]; br[j] = ar[j]; }
+            }
         }
     }
 }
