@@ -20,6 +20,9 @@
 // ahead: 3 slabs to land).  The two DMA cursors run independently and both cross into the workgroup's next tile early.
 // k is walked in the same order as conv_igemm_dma.hip (slice outer, tap inner) with the same MFMA → identical bits.
 #include "conv_dma_common.h"
+#ifndef MNET_STRIP_EPI_IN_STAGE
+#define MNET_STRIP_EPI_IN_STAGE 1
+#endif
 
 template <int BP> struct StripCap { static constexpr int MINW = BP == 256 ? 16 : 32; static constexpr int ROWS = BP + 2 * (BP / MINW); };
 
@@ -347,7 +350,17 @@ __global__ void __launch_bounds__(WC * WP * 64, WC * WP / 4) conv_strip_kernel(c
         c_sst ^= 1;
         int co0, pix0;
         tile_coords(c_v, co0, pix0);
-        if constexpr (MX) dma_epilogue_mx<BC, BP, WC, WP, FC, FP, (XB == 1024 ? 16 : 64)>(p, acc32, co0, pix0, wc, wp, lane, XB ? smem + 2 * WBYTES + 2 * SBYTES + wave * XB : nullptr);
+        if constexpr (MX) {
+            if constexpr (MNET_STRIP_EPI_IN_STAGE && XB == 1024 && SBYTES >= NW * 4096) {
+                // round 6: the 64x512 tile has 1 KiB of scratch per wave left behind its stages — the epilogue's 64-lane transposition round became four 16-lane rounds (one
+                // LDS round trip and one 256-byte store instruction each).  The strip stage the tile's last filter row was read from is free from here until the next tile's
+                // second strip is requested (after that tile's first slab barrier): 4 KiB per wave of it are the scratch of the full-size round.  (c_sst already points at the
+                // NEXT tile's first strip, which may be landing: the other stage is the consumed one.)
+                __syncthreads();                                   // everyone has read the last strip
+                dma_epilogue_mx<BC, BP, WC, WP, FC, FP, 64>(p, acc32, co0, pix0, wc, wp, lane, smem + 2 * WBYTES + (c_sst ^ 1) * SBYTES + wave * 4096);
+            } else
+            dma_epilogue_mx<BC, BP, WC, WP, FC, FP, (XB == 1024 ? 16 : 64)>(p, acc32, co0, pix0, wc, wp, lane, XB ? smem + 2 * WBYTES + 2 * SBYTES + wave * XB : nullptr);
+        }
         else dma_epilogue<BC, BP, WC, WP, 16, 0, FC, FP, X3>(p, acc, acc32_unused, co0, pix0, wc, wp, lane);
     }
 }
