@@ -18,6 +18,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--shape", default="64,64,1024,256,256")
     ap.add_argument("--zeros", action="store_true")
+    ap.add_argument("--epilogue", default="plain", choices=["plain", "gn", "residual", "scales", "all"], help="which build of the tile: extra epilogue terms of the launch")
     a = ap.parse_args()
     from marconet_amd import _lib, ops, packing
     n, h, w, cin, cout = (int(v) for v in a.shape.split(","))
@@ -32,13 +33,17 @@ def main():
     out = torch.empty((n, h, w, cout), dtype=packing.MX_DTYPE, device=dev)
     bias = torch.zeros(cout, device=dev)
     algo = _lib.ALGO_DMA_CFG16 + 0
+    kw = {}
+    if a.epilogue in ("gn", "all"): kw["gn_partial"] = ops.gn_partial_buffer(n, h, w, cout, dev)
+    if a.epilogue in ("residual", "all"): kw["residual"] = ops.convert(torch.randn((n, h, w, cout), device=dev), packing.MX_DTYPE)
+    if a.epilogue in ("scales", "all"): kw["out_scale"] = torch.rand((n, cout), device=dev) + 0.5; kw["post_scale"] = torch.rand((n, cout), device=dev) + 0.5
     for _ in range(2):
-        ops.conv2d(xs, ws, cout, 3, 3, (1, 1), (1, 1), bias=bias, act=ops.ACT_LRELU, out=out, algo=algo)
+        ops.conv2d(xs, ws, cout, 3, 3, (1, 1), (1, 1), bias=bias, act=ops.ACT_LRELU, out=out, algo=algo, **kw)
     torch.cuda.synchronize()
     s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     s.record()
     for _ in range(5):
-        ops.conv2d(xs, ws, cout, 3, 3, (1, 1), (1, 1), bias=bias, act=ops.ACT_LRELU, out=out, algo=algo)
+        ops.conv2d(xs, ws, cout, 3, 3, (1, 1), (1, 1), bias=bias, act=ops.ACT_LRELU, out=out, algo=algo, **kw)
     e.record()
     torch.cuda.synchronize()
     ms = s.elapsed_time(e) / 5
